@@ -1,0 +1,153 @@
+/*
+ * vf_hip.h -- C-ABI of the MI355X-native terrain rasteriser (libvf_hip.so).
+ *
+ * This is the drop-in boundary underneath the reference's `_vulkan_forge` extension module:
+ * plain pointers and sizes, opaque handles, int status codes; no C++/torch/pybind types.
+ * The reference has no C-ABI of its own (its boundary is PyO3, src/lib.rs:961-976); each entry
+ * point below cites the reference code it replaces.  A Rust host (as BASELINE.json's north_star
+ * words it) binds this header with `extern "C"` unchanged -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns VF_OK (0) or a negative VF_ERR_* code; vf_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure on the calling thread.
+ *   - host buffers are caller-owned and only borrowed for the duration of the call; device
+ *     buffers passed to *_device entry points are borrowed until replaced or the object dies.
+ *   - `stream` arguments are `hipStream_t` passed as `void*`; NULL = the object's own stream.
+ *     Calls on one handle are not re-entrant.  Rendering is asynchronous on the stream; the
+ *     read_* entry points synchronise.
+ *   - no CPU fallback exists: without a HIP device vf_ctx_create fails with VF_ERR_NO_DEVICE.
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_OK 0
+#define VF_ERR_NO_DEVICE (-1) /* no HIP device / runtime: reference message "No suitable GPU adapter" (src/terrain/mod.rs:285) */
+#define VF_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define VF_ERR_INVALID (-3)   /* bad argument */
+#define VF_ERR_NOMEM (-4)
+
+typedef struct vf_ctx vf_ctx;         /* one HIP device + default stream; replaces the wgpu Instance/Adapter/Device/Queue
+                                         (src/terrain/mod.rs:277-294, src/scene/mod.rs:62-70, src/lib.rs:23-61) */
+typedef struct vf_terrain vf_terrain; /* render target + pipeline state + mesh + bind groups of TerrainSpike/Scene
+                                         (src/terrain/mod.rs:221-253, src/scene/mod.rs:25-55) */
+
+typedef struct vf_device_info {
+    char name[256];
+    char arch[64];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    int32_t device_ordinal;
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t clock_khz;
+    uint64_t total_mem_bytes;
+    uint64_t lds_bytes_per_cu;
+    int32_t pci_bus_id;
+    int32_t pci_device_id;
+} vf_device_info;
+
+/* per-kernel device time of the LAST vf_terrain_render with timing enabled (HIP events on the render stream) */
+typedef struct vf_timings {
+    float geometry_ms;  /* fused vertex + triangle setup + small-triangle raster kernel */
+    float generic_ms;   /* clipped / large-triangle raster kernel */
+    float resolve_ms;   /* fragment (visibility -> RGBA8) kernel */
+    float total_ms;     /* first launch -> RGBA8 complete */
+    uint32_t generic_prims; /* primitives routed to the generic kernel */
+    uint32_t culled_blocks; /* grid blocks rejected by the screen/shard bound test */
+} vf_timings;
+
+const char *vf_last_error(void);
+
+/* ---- context ----------------------------------------------------------------------------- */
+/* replaces wgpu adapter enumeration (src/lib.rs:746-777) */
+int vf_device_count(int *count);
+int vf_device_query(int device_ordinal, vf_device_info *out);
+/* replaces Instance::new + request_adapter + request_device (src/terrain/mod.rs:277-294) */
+int vf_ctx_create(int device_ordinal, vf_ctx **out);
+void vf_ctx_destroy(vf_ctx *ctx);
+int vf_ctx_device_info(const vf_ctx *ctx, vf_device_info *out);
+
+/* ---- terrain object ---------------------------------------------------------------------- */
+/*
+ * Replaces TerrainSpike::new / Scene::new minus the Python-side validation
+ * (src/terrain/mod.rs:259-407, src/scene/mod.rs:60-206): colour target W x H (Rgba8UnormSrgb),
+ * fixed pipeline state (src/terrain/pipeline.rs:97-139), the procedural n x n grid of
+ * build_grid_xyuv (src/terrain/mod.rs:553-598; never materialised), the 256x1 LUT
+ * (ColormapLUT::new, src/terrain/mod.rs:31-110).  lut_is_srgb = 1: bytes are sRGB-encoded and
+ * decoded per texel before filtering (Rgba8UnormSrgb); 0: bytes are used as UNORM (the
+ * VF_FORCE_LUT_UNORM fallback).  The height texture starts as a 1x1 zero texel
+ * (src/terrain/mod.rs:342-378); uniforms start zeroed -- call vf_terrain_set_uniforms.
+ * grid < 2 is raised to 2 like the reference (`.max(2)`).
+ */
+int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t grid,
+                      const uint8_t lut_rgba8[1024], int lut_is_srgb, vf_terrain **out);
+void vf_terrain_destroy(vf_terrain *t);
+
+/* queue.write_buffer(ubo, TerrainUniforms) -- 44 floats, layout of src/terrain/mod.rs:114-123 */
+int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44]);
+
+/* Scene::set_height_from_r32f (src/scene/mod.rs:226-276): R32F texture (th rows x tw cols, tightly
+ * packed float32, no 256-byte row padding needed), nearest, clamp-to-edge.  Copies host -> HBM. */
+int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, uint32_t th);
+/* same, borrowing a texture already resident in HBM (e.g. a torch tensor's data_ptr) */
+int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_t tw, uint32_t th);
+
+/* Multi-GPU screen split (new; the reference is single-device).  Pixel row y belongs to this
+ * object iff ((y / band_h) % nranks) == rank; owned rows are stored densely ("local rows") in
+ * band order.  band_h must be a power of two.  Default: rank 0 of 1 (all rows). */
+int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h);
+int vf_terrain_local_rows(const vf_terrain *t, uint32_t *rows);
+
+/* Render into a caller-provided device buffer of local_rows*W*4 bytes (NULL = internal buffer). */
+int vf_terrain_set_output_device(vf_terrain *t, void *dev_rgba);
+int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba);
+
+/*
+ * The render pass of render_png (src/terrain/mod.rs:412-437, src/scene/mod.rs:280-298): clear to
+ * linear (0.02,0.02,0.03,1), one indexed draw of 6(n-1)^2 indices, vs_main / raster / fs_main
+ * (src/shaders/terrain.wgsl:44-91), sRGB store.  Leaves tightly packed RGBA8 (local rows) in HBM.
+ * Asynchronous on `stream`.
+ */
+int vf_terrain_render(vf_terrain *t, void *stream);
+int vf_terrain_sync(vf_terrain *t);
+
+/* copy_texture_to_buffer + map + un-pad (src/terrain/mod.rs:439-485): local rows [y0, y0+rows)
+ * into dst (rows*W*4 bytes).  Synchronises the last render. */
+int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows);
+/* debug/parity: per-pixel visible primitive id + 1 (0 = background) of the last render, local rows */
+int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
+
+int vf_terrain_enable_timing(vf_terrain *t, int enable);
+int vf_terrain_timings(vf_terrain *t, vf_timings *out);
+
+/* ---- grid_generate ----------------------------------------------------------------------- */
+/* make_grid (src/terrain/mesh.rs:35-90) computed on the GPU; outputs as the PyO3 wrapper returns
+ * them (:149-203): xy (nx*nz,2) f32, uv (nx*nz,2) f32, idx 6(nx-1)(nz-1) u32.  Argument validation
+ * (ValueError strings) is done by the host layer.  Host-pointer form copies back; device form
+ * leaves results in HBM. */
+int vf_grid_generate(vf_ctx *ctx, uint32_t nx, uint32_t nz, float dx, float dy,
+                     float *xy, float *uv, uint32_t *idx);
+int vf_grid_generate_device(vf_ctx *ctx, uint32_t nx, uint32_t nz, float dx, float dy,
+                            float *dev_xy, float *dev_uv, uint32_t *dev_idx, void *stream);
+
+/* ---- triangle smoke path ------------------------------------------------------------------ */
+/* Renderer::render_triangle_rgba (src/lib.rs:286-309, :685-721; src/shaders/triangle.wgsl):
+ * white clear, one colour-varying triangle, tightly packed (H,W,4) u8 into host memory. */
+int vf_triangle_render(vf_ctx *ctx, uint32_t width, uint32_t height, uint8_t *rgba_host);
+
+/* ---- multi-GPU helper --------------------------------------------------------------------- */
+/* De-interleave a rank-major gather buffer [nranks][local_rows][W][4] into the final (H,W,4)
+ * image on the device (used after an RCCL all-gather/gather when receiving in place is not
+ * possible).  All pointers are device pointers. */
+int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width,
+                           uint32_t height, uint32_t nranks, uint32_t band_h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

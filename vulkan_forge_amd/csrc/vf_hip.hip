@@ -1,0 +1,593 @@
+// vf_hip.hip -- C-ABI (include/vf_hip.h) over the gfx950 kernels in vf_kernels.h.
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include "../../include/vf_hip.h"
+#include "vf_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace vf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define VF_HIP_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(VF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+double eotf_d(double s) { return s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4); }
+
+struct SrgbTables {
+    float decode[256];
+    float thresh[256];
+    SrgbTables()
+    {
+        for (int k = 0; k < 256; ++k) {
+            decode[k] = (float)eotf_d((double)k / 255.0);
+            thresh[k] = k == 0 ? -INFINITY : (float)eotf_d(((double)k - 0.5) / 255.0);
+        }
+    }
+    uint32_t encode(float c) const
+    {
+        uint32_t k = 0;
+        while (k < 255 && c >= thresh[k + 1]) ++k;
+        return k;
+    }
+};
+const SrgbTables &tables()
+{
+    static const SrgbTables t;
+    return t;
+}
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+uint32_t ilog2(uint32_t v)
+{
+    uint32_t s = 0;
+    while ((1u << s) < v) ++s;
+    return s;
+}
+
+} // namespace
+
+struct vf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    float *d_thresh = nullptr;   // 256 sRGB store thresholds
+};
+
+struct vf_terrain {
+    vf_ctx *ctx = nullptr;
+    uint32_t W = 0, H = 0, n = 0;
+    uint32_t nbx = 0, nblocks = 0;
+    uint64_t nprims = 0;
+    bool use_tags = true;
+    uint32_t frame = 0;           // frames rendered since the last visibility clear
+    // shard
+    uint32_t rank = 0, nranks = 1, band_h = 64, local_rows = 0;
+    // uniforms
+    float u[44];
+    bool have_uniforms = false;
+    // device state
+    float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
+    int32_t *d_txi = nullptr, *d_tyj = nullptr;
+    float *d_height_own = nullptr;
+    const float *d_height = nullptr;
+    uint32_t tw = 1, th = 1;
+    bool bounds_dirty = true;
+    float2 *d_bounds = nullptr;
+    float *d_lut = nullptr;       // 256*3 linear floats
+    uint32_t *d_vis = nullptr;
+    uint32_t *d_rgba_own = nullptr;
+    uint32_t *d_rgba = nullptr;
+    uint32_t *d_slow = nullptr;
+    uint32_t *d_counters = nullptr;   // [0] slow count, [1] culled blocks, [2],[3] last frame's copies
+    uint32_t *d_scratch = nullptr;    // decode target for read_visibility
+    size_t vis_capacity_px = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipStream_t last_stream = nullptr;
+    bool rendered = false;
+};
+
+extern "C" {
+
+const char *vf_last_error(void) { return g_err.c_str(); }
+
+int vf_device_count(int *count)
+{
+    if (!count) return fail(VF_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(VF_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return VF_OK;
+}
+
+static void fill_info(int ordinal, const hipDeviceProp_t &p, vf_device_info *out)
+{
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", p.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    out->device_ordinal = ordinal;
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->clock_khz = p.clockRate;
+    out->total_mem_bytes = p.totalGlobalMem;
+    out->lds_bytes_per_cu = p.maxSharedMemoryPerMultiProcessor;
+    out->pci_bus_id = p.pciBusID;
+    out->pci_device_id = p.pciDeviceID;
+}
+
+int vf_device_query(int device_ordinal, vf_device_info *out)
+{
+    if (!out) return fail(VF_ERR_INVALID, "out is NULL");
+    int n = 0;
+    int rc = vf_device_count(&n);
+    if (rc != VF_OK) return rc;
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(VF_ERR_NO_DEVICE, "No suitable GPU adapter");
+    hipDeviceProp_t p;
+    VF_HIP_TRY(hipGetDeviceProperties(&p, device_ordinal));
+    fill_info(device_ordinal, p, out);
+    return VF_OK;
+}
+
+int vf_ctx_create(int device_ordinal, vf_ctx **out)
+{
+    if (!out) return fail(VF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n)
+        return fail(VF_ERR_NO_DEVICE, "No suitable GPU adapter");   // reference string, src/terrain/mod.rs:285
+    vf_ctx *c = new (std::nothrow) vf_ctx;
+    if (!c) return fail(VF_ERR_NOMEM, "out of host memory");
+    c->device = device_ordinal;
+    hipError_t err = hipSetDevice(device_ordinal);
+    if (err == hipSuccess) err = hipGetDeviceProperties(&c->prop, device_ordinal);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMalloc(&c->d_thresh, 256 * sizeof(float));
+    if (err == hipSuccess) err = hipMemcpy(c->d_thresh, tables().thresh, 256 * sizeof(float), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        std::string m = std::string("context creation failed: ") + hipGetErrorString(err);
+        vf_ctx_destroy(c);
+        return fail(VF_ERR_HIP, m);
+    }
+    *out = c;
+    return VF_OK;
+}
+
+void vf_ctx_destroy(vf_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_thresh) (void)hipFree(c->d_thresh);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vf_ctx_device_info(const vf_ctx *ctx, vf_device_info *out)
+{
+    if (!ctx || !out) return fail(VF_ERR_INVALID, "NULL argument");
+    fill_info(ctx->device, ctx->prop, out);
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+static uint32_t compute_local_rows(uint32_t H, uint32_t rank, uint32_t nranks, uint32_t band_h)
+{
+    if (nranks <= 1) return H;
+    uint32_t rows = 0;
+    for (uint32_t b = 0; b * band_h < H; ++b)
+        if (b % nranks == rank) rows += (b + 1) * band_h <= H ? band_h : H - b * band_h;
+    return rows;
+}
+
+static int alloc_targets(vf_terrain *t)
+{
+    // the largest per-rank share any shard setting can produce is the full frame; allocate once for it
+    size_t npx = (size_t)t->W * t->H;
+    if (npx <= t->vis_capacity_px) return VF_OK;
+    VF_HIP_TRY(hipMalloc(&t->d_vis, npx * sizeof(uint32_t)));
+    VF_HIP_TRY(hipMalloc(&t->d_rgba_own, npx * sizeof(uint32_t)));
+    VF_HIP_TRY(hipMalloc(&t->d_scratch, npx * sizeof(uint32_t)));
+    VF_HIP_TRY(hipMemset(t->d_vis, 0, npx * sizeof(uint32_t)));
+    t->vis_capacity_px = npx;
+    if (!t->d_rgba) t->d_rgba = t->d_rgba_own;
+    return VF_OK;
+}
+
+static AxisTables axis(const vf_terrain *t)
+{
+    AxisTables A;
+    A.xs = t->d_xs; A.sinx = t->d_sinx; A.cosz = t->d_cosz; A.txi = t->d_txi; A.tyj = t->d_tyj;
+    return A;
+}
+
+static int refresh_tables(vf_terrain *t, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_axis_tables, dim3((t->n + 255) / 256), dim3(256), 0, s, t->n, t->tw, t->th, t->d_xs, t->d_sinx,
+                       t->d_cosz, t->d_txi, t->d_tyj);
+    VF_HIP_TRY(hipGetLastError());
+    t->bounds_dirty = true;
+    return VF_OK;
+}
+
+int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t grid, const uint8_t lut_rgba8[1024],
+                      int lut_is_srgb, vf_terrain **out)
+{
+    if (!ctx || !out || !lut_rgba8) return fail(VF_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return fail(VF_ERR_INVALID, "width/height must be in 1..16384");
+    uint32_t n = grid < 2 ? 2 : grid;   // `.max(2)`, src/terrain/mod.rs:260
+    if (n > 8192) return fail(VF_ERR_INVALID, "grid must be <= 8192");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    vf_terrain *t = new (std::nothrow) vf_terrain;
+    if (!t) return fail(VF_ERR_NOMEM, "out of host memory");
+    t->ctx = ctx; t->W = width; t->H = height; t->n = n;
+    t->nbx = (n - 1 + kBlockCells - 1) / kBlockCells;
+    t->nblocks = t->nbx * t->nbx;
+    t->nprims = 2ull * (n - 1) * (n - 1);
+    t->use_tags = t->nprims < (1ull << kTagShift);
+    t->local_rows = height;
+    std::memset(t->u, 0, sizeof t->u);
+
+    float lut[768];
+    for (int i = 0; i < 256; ++i)
+        for (int ch = 0; ch < 3; ++ch)
+            lut[3 * i + ch] = lut_is_srgb ? tables().decode[lut_rgba8[4 * i + ch]] : (float)lut_rgba8[4 * i + ch] / 255.0f;
+    const float zero = 0.0f;
+
+    hipError_t err = hipSuccess;
+    auto A = [&](void **p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(p, bytes); };
+    A((void **)&t->d_xs, n * sizeof(float));
+    A((void **)&t->d_sinx, n * sizeof(float));
+    A((void **)&t->d_cosz, n * sizeof(float));
+    A((void **)&t->d_txi, n * sizeof(int32_t));
+    A((void **)&t->d_tyj, n * sizeof(int32_t));
+    A((void **)&t->d_height_own, sizeof(float));
+    A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
+    A((void **)&t->d_lut, sizeof lut);
+    A((void **)&t->d_slow, t->nprims * sizeof(uint32_t));
+    A((void **)&t->d_counters, 4 * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
+    if (err == hipSuccess) err = hipMemset(t->d_counters, 0, 4 * sizeof(uint32_t));
+    for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[k]);
+    if (err != hipSuccess) {
+        std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
+        vf_terrain_destroy(t);
+        return fail(err == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, m);
+    }
+    t->d_height = t->d_height_own; t->tw = 1; t->th = 1;
+    int rc = alloc_targets(t);
+    if (rc == VF_OK) rc = refresh_tables(t, ctx->stream);
+    if (rc == VF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(VF_ERR_HIP, "table setup failed");
+    if (rc != VF_OK) { std::string keep = g_err; vf_terrain_destroy(t); g_err = keep; return rc; }
+    *out = t;
+    return VF_OK;
+}
+
+void vf_terrain_destroy(vf_terrain *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_lut,
+                     t->d_vis, t->d_rgba_own, t->d_slow, t->d_counters, t->d_scratch };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
+    delete t;
+}
+
+int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44])
+{
+    if (!t || !uniforms) return fail(VF_ERR_INVALID, "NULL argument");
+    std::memcpy(t->u, uniforms, sizeof t->u);
+    t->have_uniforms = true;
+    return VF_OK;
+}
+
+static int set_height_common(vf_terrain *t, uint32_t tw, uint32_t th)
+{
+    bool resized = tw != t->tw || th != t->th;
+    t->tw = tw; t->th = th;
+    if (resized) return refresh_tables(t, t->ctx->stream);
+    t->bounds_dirty = true;
+    return VF_OK;
+}
+
+int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, uint32_t th)
+{
+    if (!t || !host_height) return fail(VF_ERR_INVALID, "NULL argument");
+    if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    size_t bytes = (size_t)tw * th * sizeof(float);
+    if ((size_t)t->tw * t->th != (size_t)tw * th || t->d_height != t->d_height_own) {
+        if (t->d_height_own) VF_HIP_TRY(hipFree(t->d_height_own));
+        t->d_height_own = nullptr;
+        VF_HIP_TRY(hipMalloc(&t->d_height_own, bytes));
+    }
+    t->d_height = t->d_height_own;
+    VF_HIP_TRY(hipMemcpyAsync(t->d_height_own, host_height, bytes, hipMemcpyHostToDevice, t->ctx->stream));
+    int rc = set_height_common(t, tw, th);
+    VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));   // host buffer is only borrowed for this call
+    return rc;
+}
+
+int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_t tw, uint32_t th)
+{
+    if (!t || !dev_height) return fail(VF_ERR_INVALID, "NULL argument");
+    if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    t->d_height = dev_height;
+    int rc = set_height_common(t, tw, th);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return VF_OK;
+}
+
+int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
+    if (!is_pow2(band_h)) return fail(VF_ERR_INVALID, "band_h must be a power of two");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    t->rank = rank; t->nranks = nranks; t->band_h = band_h;
+    t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
+    // the row -> local row mapping changed: stale visibility words must not survive
+    VF_HIP_TRY(hipMemset(t->d_vis, 0, t->vis_capacity_px * sizeof(uint32_t)));
+    t->frame = 0;
+    return VF_OK;
+}
+
+int vf_terrain_local_rows(const vf_terrain *t, uint32_t *rows)
+{
+    if (!t || !rows) return fail(VF_ERR_INVALID, "NULL argument");
+    *rows = t->local_rows;
+    return VF_OK;
+}
+
+int vf_terrain_set_output_device(vf_terrain *t, void *dev_rgba)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    t->d_rgba = dev_rgba ? (uint32_t *)dev_rgba : t->d_rgba_own;
+    return VF_OK;
+}
+
+int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba)
+{
+    if (!t || !dev_rgba) return fail(VF_ERR_INVALID, "NULL argument");
+    *dev_rgba = t->d_rgba;
+    return VF_OK;
+}
+
+static void build_params(const vf_terrain *t, FrameParams &P)
+{
+    const float *u = t->u;
+    std::memcpy(P.view, u, 64);
+    std::memcpy(P.proj, u + 16, 64);
+    P.spacing = std::fmax(u[36], 1e-8f);       // terrain.wgsl:46
+    P.exag = u[38];
+    P.h_range = std::fmax(u[37], 1e-8f);       // terrain.wgsl:71
+    P.exposure = u[35];
+    {   // L = normalize(sun), terrain.wgsl:83 -- uniform per frame, evaluated once with the same IEEE ops
+        float sx = u[32], sy = u[33], sz = u[34];
+        float inv = 1.0f / std::sqrt(std::fmaf(sz, sz, std::fmaf(sy, sy, sx * sx)));
+        P.Lx = sx * inv; P.Ly = sy * inv; P.Lz = sz * inv;
+    }
+    P.hw = 0.5f * (float)t->W; P.hh = 0.5f * (float)t->H;
+    P.n = t->n; P.nm1 = t->n - 1;
+    P.W = t->W; P.H = t->H; P.tw = t->tw; P.th = t->th;
+    P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
+    P.local_rows = t->local_rows;
+    P.tag = 0;
+    const SrgbTables &T = tables();
+    P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
+    P.slow_cap = (uint32_t)(t->nprims > 0xFFFFFFFFull ? 0xFFFFFFFFull : t->nprims);
+}
+
+int vf_terrain_render(vf_terrain *t, void *stream)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
+    FrameParams P;
+    build_params(t, P);
+    AxisTables A = axis(t);
+
+    if (t->bounds_dirty) {
+        hipLaunchKernelGGL(k_block_bounds, dim3(t->nblocks), dim3(256), 0, s, t->n, t->nbx, t->tw, A, t->d_height, t->d_bounds);
+        VF_HIP_TRY(hipGetLastError());
+        t->bounds_dirty = false;
+    }
+    const size_t npx = (size_t)t->local_rows * t->W;
+    if (t->use_tags) {
+        if (t->frame >= 127) {   // tag space exhausted: one real clear, then start over
+            VF_HIP_TRY(hipMemsetAsync(t->d_vis, 0, npx * sizeof(uint32_t), s));
+            t->frame = 0;
+        }
+        P.tag = (t->frame + 1u) << kTagShift;
+    } else {
+        VF_HIP_TRY(hipMemsetAsync(t->d_vis, 0, npx * sizeof(uint32_t), s));
+    }
+    t->frame++;
+
+    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[0], s));
+    hipLaunchKernelGGL(k_geometry, dim3(t->nblocks), dim3(kGeomThreads), 0, s, P, A, t->d_height, t->d_bounds, t->nbx,
+                       t->d_vis, t->d_slow, t->d_counters);
+    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[1], s));
+    hipLaunchKernelGGL(k_generic, dim3(1024), dim3(256), 0, s, P, A, t->d_height, t->d_vis, t->d_slow, t->d_counters);
+    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[2], s));
+    if (npx % 4 == 0 && t->W % 4 == 0)
+        hipLaunchKernelGGL(k_resolve<4>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, s, P, A, t->d_height, t->d_lut,
+                           t->ctx->d_thresh, t->d_vis, t->d_rgba, t->d_counters);
+    else
+        hipLaunchKernelGGL(k_resolve<1>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, P, A, t->d_height, t->d_lut,
+                           t->ctx->d_thresh, t->d_vis, t->d_rgba, t->d_counters);
+    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[3], s));
+    VF_HIP_TRY(hipGetLastError());
+    t->last_stream = s;
+    t->rendered = true;
+    return VF_OK;
+}
+
+int vf_terrain_sync(vf_terrain *t)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    return VF_OK;
+}
+
+int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows)
+{
+    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    if ((uint64_t)y0 + rows > t->local_rows) return fail(VF_ERR_INVALID, "row range outside the local rows");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipMemcpy(dst, t->d_rgba + (size_t)y0 * t->W, (size_t)rows * t->W * 4, hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
+{
+    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    FrameParams P;
+    build_params(t, P);
+    P.tag = t->use_tags ? (t->frame << kTagShift) : 0u;   // tag of the frame just rendered
+    const size_t npx = (size_t)t->local_rows * t->W;
+    hipLaunchKernelGGL(k_decode_vis, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, t->ctx->stream, P, t->d_vis, t->d_scratch);
+    VF_HIP_TRY(hipGetLastError());
+    VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    VF_HIP_TRY(hipMemcpy(dst, t->d_scratch, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_terrain_enable_timing(vf_terrain *t, int enable)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    t->timing = enable != 0;
+    return VF_OK;
+}
+
+int vf_terrain_timings(vf_terrain *t, vf_timings *out)
+{
+    if (!t || !out) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipEventSynchronize(t->ev[3]));
+    VF_HIP_TRY(hipEventElapsedTime(&out->geometry_ms, t->ev[0], t->ev[1]));
+    VF_HIP_TRY(hipEventElapsedTime(&out->generic_ms, t->ev[1], t->ev[2]));
+    VF_HIP_TRY(hipEventElapsedTime(&out->resolve_ms, t->ev[2], t->ev[3]));
+    VF_HIP_TRY(hipEventElapsedTime(&out->total_ms, t->ev[0], t->ev[3]));
+    uint32_t c[4];
+    VF_HIP_TRY(hipMemcpy(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->generic_prims = c[2];
+    out->culled_blocks = c[3];
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+int vf_grid_generate_device(vf_ctx *ctx, uint32_t nx, uint32_t nz, float dx, float dy, float *dev_xy, float *dev_uv,
+                            uint32_t *dev_idx, void *stream)
+{
+    if (!ctx || !dev_xy || !dev_uv || !dev_idx) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nx < 2 || nz < 2) return fail(VF_ERR_INVALID, "nx and nz must be >= 2");
+    if ((uint64_t)nx * nz > 0xFFFFFFFFull) return fail(VF_ERR_INVALID, "vertex count exceeds u32 indices");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    size_t nv = (size_t)nx * nz, nc = (size_t)(nx - 1) * (nz - 1);
+    hipLaunchKernelGGL(k_grid_vertices, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, nx, nz, dx, dy, (float2 *)dev_xy, (float2 *)dev_uv);
+    hipLaunchKernelGGL(k_grid_indices, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, nx, nz, dev_idx);
+    VF_HIP_TRY(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_grid_generate(vf_ctx *ctx, uint32_t nx, uint32_t nz, float dx, float dy, float *xy, float *uv, uint32_t *idx)
+{
+    if (!ctx || !xy || !uv || !idx) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nx < 2 || nz < 2) return fail(VF_ERR_INVALID, "nx and nz must be >= 2");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    size_t nv = (size_t)nx * nz, ni = 6 * (size_t)(nx - 1) * (nz - 1);
+    float *d_xy = nullptr, *d_uv = nullptr;
+    uint32_t *d_idx = nullptr;
+    hipError_t err = hipMalloc(&d_xy, nv * 8);
+    if (err == hipSuccess) err = hipMalloc(&d_uv, nv * 8);
+    if (err == hipSuccess) err = hipMalloc(&d_idx, ni * 4);
+    int rc = VF_OK;
+    if (err != hipSuccess) rc = fail(VF_ERR_NOMEM, std::string("grid_generate allocation failed: ") + hipGetErrorString(err));
+    if (rc == VF_OK) rc = vf_grid_generate_device(ctx, nx, nz, dx, dy, d_xy, d_uv, d_idx, ctx->stream);
+    if (rc == VF_OK) {
+        err = hipStreamSynchronize(ctx->stream);
+        if (err == hipSuccess) err = hipMemcpy(xy, d_xy, nv * 8, hipMemcpyDeviceToHost);
+        if (err == hipSuccess) err = hipMemcpy(uv, d_uv, nv * 8, hipMemcpyDeviceToHost);
+        if (err == hipSuccess) err = hipMemcpy(idx, d_idx, ni * 4, hipMemcpyDeviceToHost);
+        if (err != hipSuccess) rc = fail(VF_ERR_HIP, std::string("grid_generate readback failed: ") + hipGetErrorString(err));
+    }
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_uv) (void)hipFree(d_uv);
+    if (d_idx) (void)hipFree(d_idx);
+    return rc;
+}
+
+int vf_triangle_render(vf_ctx *ctx, uint32_t width, uint32_t height, uint8_t *rgba_host)
+{
+    if (!ctx || !rgba_host) return fail(VF_ERR_INVALID, "NULL argument");
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return fail(VF_ERR_INVALID, "width/height must be in 1..16384");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    size_t npx = (size_t)width * height;
+    uint32_t *d = nullptr;
+    VF_HIP_TRY(hipMalloc(&d, npx * 4));
+    hipLaunchKernelGGL(k_triangle, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, width, height, ctx->d_thresh, d);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err == hipSuccess) err = hipMemcpy(rgba_host, d, npx * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (err != hipSuccess) return fail(VF_ERR_HIP, std::string("triangle render failed: ") + hipGetErrorString(err));
+    return VF_OK;
+}
+
+int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width, uint32_t height,
+                           uint32_t nranks, uint32_t band_h, void *stream)
+{
+    if (!ctx || !dev_gathered || !dev_image) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!is_pow2(band_h) || nranks == 0) return fail(VF_ERR_INVALID, "band_h must be a power of two, nranks > 0");
+    if (width % 4 != 0) return fail(VF_ERR_INVALID, "width must be a multiple of 4");
+    if (height % (band_h * nranks) != 0) return fail(VF_ERR_INVALID, "height must be a multiple of band_h*nranks");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t row_vec4 = width / 4;
+    size_t nvec = (size_t)height * row_vec4;
+    hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const uint4 *)dev_gathered,
+                       (uint4 *)dev_image, row_vec4, height, nranks, ilog2(band_h), band_h, height / nranks);
+    VF_HIP_TRY(hipGetLastError());
+    return VF_OK;
+}
+
+} // extern "C"

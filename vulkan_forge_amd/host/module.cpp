@@ -1,0 +1,409 @@
+// module.cpp -- CPython extension `_vulkan_forge`: the C++ host side above the C-ABI (include/vf_hip.h).
+//
+// Mirrors the Python-visible surface the reference registers in src/lib.rs:961-976 (names, signatures,
+// return types, exception classes and messages) for the terrain-raster hot path:
+//   classes   Renderer (triangle path), TerrainSpike, Scene
+//   functions enumerate_adapters, device_probe, grid_generate, colormap_supported,
+//             camera_look_at, camera_perspective, camera_view_proj
+// All rendering goes through libvf_hip.so; there is no CPU fallback -- without a HIP device every
+// object that needs the GPU raises RuntimeError("No suitable GPU adapter") like the reference.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vf_hip.h"
+#include "../data/colormaps_rgba8.h"
+#include "camera.hpp"
+#include "png_writer.hpp"
+
+namespace py = pybind11;
+using namespace vfh;
+
+namespace {
+
+// ---- colormap registry: src/colormap/mod.rs --------------------------------------------------
+const char *const kSupported[3] = { "viridis", "magma", "terrain" };   // :7 (case-sensitive)
+
+std::string unknown_colormap(const std::string &name)
+{
+    return "Unknown colormap '" + name + "'. Supported: viridis, magma, terrain";   // :16,:32,:39
+}
+const uint8_t *resolve_lut(const std::string &name)
+{
+    if (name == "viridis") return VF_LUT_VIRIDIS;
+    if (name == "magma") return VF_LUT_MAGMA;
+    if (name == "terrain") return VF_LUT_TERRAIN;
+    throw std::runtime_error(unknown_colormap(name));
+}
+// to_linear_u8_rgba, src/colormap/mod.rs:59-79 (the Rgba8Unorm fallback bytes)
+void to_linear_u8_rgba(const uint8_t *src, uint8_t *dst)
+{
+    for (int i = 0; i < 256; ++i) {
+        for (int ch = 0; ch < 3; ++ch) {
+            float s = (float)src[4 * i + ch] / 255.0f;
+            float l = s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f);
+            l = l < 0.0f ? 0.0f : (l > 1.0f ? 1.0f : l);
+            dst[4 * i + ch] = (uint8_t)(l * 255.0f + 0.5f);
+        }
+        dst[4 * i + 3] = src[4 * i + 3];
+    }
+}
+
+// ---- HIP context: one per process and device, like the reference's OnceCell (src/lib.rs:23-61) ----
+[[noreturn]] void raise_vf(int rc)
+{
+    if (rc == VF_ERR_NO_DEVICE) throw std::runtime_error("No suitable GPU adapter");
+    throw std::runtime_error(std::string(vf_last_error()));
+}
+void check(int rc) { if (rc != VF_OK) raise_vf(rc); }
+
+int device_ordinal()
+{
+    const char *e = std::getenv("VF_HIP_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
+struct Ctx {
+    vf_ctx *c = nullptr;
+    ~Ctx() { /* process lifetime: the HIP runtime may already be torn down at exit */ }
+};
+vf_ctx *global_ctx()
+{
+    static std::mutex mu;
+    static Ctx ctx;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ctx.c) check(vf_ctx_create(device_ordinal(), &ctx.c));
+    return ctx.c;
+}
+
+Vec3 v3(const std::tuple<float, float, float> &t) { return { std::get<0>(t), std::get<1>(t), std::get<2>(t) }; }
+
+// mat4_to_numpy, src/camera.rs:94-112: (4,4) float32 C-contiguous in mathematical (row, col) indexing
+py::array_t<float> mat4_to_numpy(const Mat4 &m)
+{
+    py::array_t<float> a({ 4, 4 });
+    auto r = a.mutable_unchecked<2>();
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) r(row, col) = m[4 * col + row];
+    return a;
+}
+
+// ---- TerrainSpike / Scene -----------------------------------------------------------------------
+class TerrainObject {
+public:
+    // kind 0: TerrainSpike::new (src/terrain/mod.rs:259-407); kind 1: Scene::new (src/scene/mod.rs:60-206)
+    TerrainObject(int kind, uint32_t width, uint32_t height, py::object grid, py::object colormap) : W(width), H(height)
+    {
+        uint32_t g = grid.is_none() ? 128u : grid.cast<uint32_t>();
+        n = g < 2 ? 2 : g;
+        std::string cmap = colormap.is_none() ? "viridis" : colormap.cast<std::string>();
+        bool known = false;
+        for (const char *s : kSupported) known |= cmap == s;
+        if (!known) throw std::runtime_error(unknown_colormap(cmap));
+        const uint8_t *srgb_bytes = resolve_lut(cmap);
+        // ColormapLUT::new format selection (src/terrain/mod.rs:45-60): sRGB sampling is always
+        // available here, so only VF_FORCE_LUT_UNORM selects the CPU-linearised UNORM bytes.
+        bool force_unorm = std::getenv("VF_FORCE_LUT_UNORM") != nullptr;
+        uint8_t lin[1024];
+        if (force_unorm) to_linear_u8_rgba(srgb_bytes, lin);
+        lut_format = force_unorm ? "Rgba8Unorm" : "Rgba8UnormSrgb";
+
+        check(vf_terrain_create(global_ctx(), W, H, n, force_unorm ? lin : srgb_bytes, force_unorm ? 0 : 1, &t));
+
+        // build_view_matrices (src/terrain/mod.rs:681-691) / SceneGlobals::default (src/scene/mod.rs:17-23,119)
+        view = look_at_rh({ 3.f, 2.f, 3.f }, { 0.f, 0.f, 0.f }, { 0.f, 1.f, 0.f });
+        proj = perspective_wgpu(to_radians(45.0f), (float)W / (float)H, 0.1f, 100.0f);
+        if (kind == 0) globals.sun_dir = normalize({ 0.5f, 1.0f, 0.3f });   // R4 override, src/terrain/mod.rs:325-327
+        push_uniforms();
+        if (kind == 1) {
+            const float dummy[4] = { 0.00f, 0.25f, 0.50f, 0.75f };   // 2x2 gradient, src/scene/mod.rs:142-189
+            check(vf_terrain_set_height(t, dummy, 2, 2));
+        }
+    }
+    ~TerrainObject() { if (t) vf_terrain_destroy(t); }
+    TerrainObject(const TerrainObject &) = delete;
+    TerrainObject &operator=(const TerrainObject &) = delete;
+
+    // src/terrain/mod.rs:498-535, src/scene/mod.rs:208-224
+    void set_camera_look_at(std::tuple<float, float, float> eye, std::tuple<float, float, float> target,
+                            std::tuple<float, float, float> up, float fovy_deg, float znear, float zfar)
+    {
+        float aspect = (float)W / (float)H;
+        validate_camera_params(v3(eye), v3(target), v3(up), fovy_deg, znear, zfar);
+        view = look_at_rh(v3(eye), v3(target), v3(up));
+        proj = perspective_wgpu(to_radians(fovy_deg), aspect, znear, zfar);
+        push_uniforms();
+    }
+
+    // Scene::set_height_from_r32f, src/scene/mod.rs:226-276
+    void set_height_from_r32f(py::object obj)
+    {
+        if (!py::isinstance<py::array>(obj)) throw py::type_error("argument 'height_r32f': expected a 2-D numpy.ndarray of float32");
+        py::array arr = py::reinterpret_borrow<py::array>(obj);
+        if (arr.ndim() != 2 || !arr.dtype().is(py::dtype::of<float>()))
+            throw py::type_error("argument 'height_r32f': expected a 2-D numpy.ndarray of float32");
+        if (!(arr.flags() & py::array::c_style)) throw std::runtime_error("height must be C-contiguous float32[H,W]");
+        uint32_t h = (uint32_t)arr.shape(0), w = (uint32_t)arr.shape(1);
+        check(vf_terrain_set_height(t, static_cast<const float *>(arr.data()), w, h));
+    }
+
+    std::vector<uint8_t> render_pixels()
+    {
+        uint32_t rows = 0;
+        check(vf_terrain_local_rows(t, &rows));
+        std::vector<uint8_t> px((size_t)rows * W * 4);
+        {
+            py::gil_scoped_release nogil;
+            int rc = vf_terrain_render(t, nullptr);
+            if (rc == VF_OK) rc = vf_terrain_read_rgba(t, px.data(), 0, rows);
+            if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
+        }
+        return px;
+    }
+
+    // render_png, src/terrain/mod.rs:409-491, src/scene/mod.rs:278-335
+    void render_png(const std::string &path)
+    {
+        uint32_t rows = 0;
+        check(vf_terrain_local_rows(t, &rows));
+        std::vector<uint8_t> px = render_pixels();
+        py::gil_scoped_release nogil;
+        write_png_rgba8(path, px.data(), W, rows);
+    }
+
+    // extension (not in the reference): the frame as (H, W, 4) uint8 without the PNG round trip
+    py::array_t<uint8_t> render_rgba()
+    {
+        uint32_t rows = 0;
+        check(vf_terrain_local_rows(t, &rows));
+        std::vector<uint8_t> px = render_pixels();
+        py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
+        std::memcpy(a.mutable_data(), px.data(), px.size());
+        return a;
+    }
+    // extension: visible primitive id + 1 per pixel of the last render (0 = background)
+    py::array_t<uint32_t> debug_visibility()
+    {
+        uint32_t rows = 0;
+        check(vf_terrain_local_rows(t, &rows));
+        py::array_t<uint32_t> a({ (py::ssize_t)rows, (py::ssize_t)W });
+        check(vf_terrain_read_visibility(t, a.mutable_data()));
+        return a;
+    }
+    // extension: multi-GPU band ownership (DESIGN.md "Sharding")
+    void set_shard(uint32_t rank, uint32_t nranks, uint32_t band_h) { check(vf_terrain_set_shard(t, rank, nranks, band_h)); }
+    py::dict last_timings()
+    {
+        vf_timings tm;
+        check(vf_terrain_timings(t, &tm));
+        py::dict d;
+        d["geometry_ms"] = tm.geometry_ms; d["generic_ms"] = tm.generic_ms; d["resolve_ms"] = tm.resolve_ms;
+        d["total_ms"] = tm.total_ms; d["generic_prims"] = tm.generic_prims; d["culled_blocks"] = tm.culled_blocks;
+        return d;
+    }
+    void enable_timing(bool on) { check(vf_terrain_enable_timing(t, on ? 1 : 0)); }
+
+    // src/terrain/mod.rs:537-546
+    py::array_t<float> debug_uniforms_f32() const
+    {
+        py::array_t<float> a(44);
+        std::memcpy(a.mutable_data(), last.data(), 44 * sizeof(float));
+        return a;
+    }
+    std::string debug_lut_format() const { return lut_format; }   // src/terrain/mod.rs:493-496
+
+private:
+    void push_uniforms()
+    {
+        last = to_uniforms(globals, view, proj);
+        check(vf_terrain_set_uniforms(t, last.data()));
+    }
+    uint32_t W, H, n = 128;
+    vf_terrain *t = nullptr;
+    Globals globals;
+    Mat4 view{}, proj{};
+    Uniforms last{};
+    std::string lut_format;
+};
+
+class TerrainSpike : public TerrainObject {
+public:
+    TerrainSpike(uint32_t w, uint32_t h, py::object grid, py::object colormap) : TerrainObject(0, w, h, grid, colormap) {}
+};
+class Scene : public TerrainObject {
+public:
+    Scene(uint32_t w, uint32_t h, py::object grid, py::object colormap) : TerrainObject(1, w, h, grid, colormap) {}
+};
+
+// ---- Renderer: the triangle smoke path (src/lib.rs:245-334, 685-721) ---------------------------------
+class Renderer {
+public:
+    Renderer(uint32_t w, uint32_t h) : W(w), H(h) { global_ctx(); }
+    std::string info() const { return "Renderer " + std::to_string(W) + "x" + std::to_string(H) + ", format=Rgba8UnormSrgb"; }
+    py::array_t<uint8_t> render_triangle_rgba()
+    {
+        py::array_t<uint8_t> a({ (py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)4 });
+        check(vf_triangle_render(global_ctx(), W, H, a.mutable_data()));
+        return a;
+    }
+    void render_triangle_png(const std::string &path)
+    {
+        std::vector<uint8_t> px((size_t)W * H * 4);
+        check(vf_triangle_render(global_ctx(), W, H, px.data()));
+        write_png_rgba8(path, px.data(), W, H);
+    }
+private:
+    uint32_t W, H;
+};
+
+// ---- module functions ------------------------------------------------------------------------------
+// grid_generate, src/terrain/mesh.rs:149-203 (validation strings :161-173 raised as ValueError)
+py::tuple grid_generate(uint32_t nx, uint32_t nz, std::tuple<float, float> spacing, py::object origin)
+{
+    if (nx < 2 || nz < 2) throw py::value_error("nx and nz must be >= 2");
+    float dx = std::get<0>(spacing), dy = std::get<1>(spacing);
+    if (!std::isfinite(dx) || !std::isfinite(dy) || dx <= 0.0f || dy <= 0.0f) throw py::value_error("spacing components must be finite and > 0");
+    std::string o = origin.is_none() ? "center" : origin.cast<std::string>();
+    if (o != "center") throw py::value_error("origin must be 'center'");
+    py::ssize_t nv = (py::ssize_t)nx * nz, ni = 6 * (py::ssize_t)(nx - 1) * (nz - 1);
+    py::array_t<float> xy({ nv, (py::ssize_t)2 }), uv({ nv, (py::ssize_t)2 });
+    py::array_t<uint32_t> idx(ni);
+    check(vf_grid_generate(global_ctx(), nx, nz, dx, dy, xy.mutable_data(), uv.mutable_data(), idx.mutable_data()));
+    return py::make_tuple(xy, uv, idx);
+}
+
+std::vector<std::string> colormap_supported() { return { "viridis", "magma", "terrain" }; }   // src/colormap/mod.rs:44-47
+
+py::array_t<float> camera_look_at(std::tuple<float, float, float> eye, std::tuple<float, float, float> target,
+                                  std::tuple<float, float, float> up)
+{
+    validate_vectors(v3(eye), v3(target), v3(up));
+    return mat4_to_numpy(look_at_rh(v3(eye), v3(target), v3(up)));
+}
+py::array_t<float> camera_perspective(float fovy_deg, float aspect, float znear, float zfar, py::object clip_space)
+{
+    std::string clip = clip_space.is_none() ? "wgpu" : clip_space.cast<std::string>();
+    validate_fovy(fovy_deg); validate_aspect(aspect); validate_near(znear); validate_far(zfar, znear);
+    bool gl = clip_is_gl(clip);
+    Mat4 p = gl ? perspective_rh_gl(to_radians(fovy_deg), aspect, znear, zfar) : perspective_wgpu(to_radians(fovy_deg), aspect, znear, zfar);
+    return mat4_to_numpy(p);
+}
+py::array_t<float> camera_view_proj(std::tuple<float, float, float> eye, std::tuple<float, float, float> target,
+                                    std::tuple<float, float, float> up, float fovy_deg, float aspect, float znear, float zfar,
+                                    py::object clip_space)
+{
+    std::string clip = clip_space.is_none() ? "wgpu" : clip_space.cast<std::string>();
+    validate_vectors(v3(eye), v3(target), v3(up));
+    validate_fovy(fovy_deg); validate_aspect(aspect); validate_near(znear); validate_far(zfar, znear);
+    bool gl = clip_is_gl(clip);
+    Mat4 v = look_at_rh(v3(eye), v3(target), v3(up));
+    Mat4 p = gl ? perspective_rh_gl(to_radians(fovy_deg), aspect, znear, zfar) : perspective_wgpu(to_radians(fovy_deg), aspect, znear, zfar);
+    return mat4_to_numpy(mat_mul(p, v));
+}
+
+// enumerate_adapters / device_probe (src/lib.rs:744-845) reported from hipGetDeviceProperties
+py::dict adapter_dict(const vf_device_info &di)
+{
+    py::dict d;
+    d["name"] = std::string(di.name);
+    d["backend"] = "HIP";
+    d["device_type"] = "DiscreteGpu";
+    d["vendor_id"] = 0x1002u;
+    d["device_id"] = (uint32_t)di.pci_device_id;
+    d["features"] = std::string("arch=") + di.arch + " wavefront=" + std::to_string(di.wavefront_size);
+    d["limits"] = "compute_units=" + std::to_string(di.compute_units) + " total_mem_bytes=" + std::to_string(di.total_mem_bytes) +
+                  " lds_bytes_per_cu=" + std::to_string(di.lds_bytes_per_cu);
+    return d;
+}
+py::list enumerate_adapters()
+{
+    py::list out;
+    int n = 0;
+    if (vf_device_count(&n) != VF_OK) return out;
+    for (int i = 0; i < n; ++i) {
+        vf_device_info di;
+        if (vf_device_query(i, &di) == VF_OK) out.append(adapter_dict(di));
+    }
+    return out;
+}
+py::dict device_probe(py::object backend)
+{
+    std::string b = backend.is_none() ? "AUTO" : backend.cast<std::string>();
+    for (auto &ch : b) ch = (char)std::toupper((unsigned char)ch);
+    py::dict d;
+    d["backend_request"] = b;
+    auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (b != "AUTO" && b != "HIP") {   // only one backend exists in this build
+        d["status"] = "unsupported"; d["message"] = "No suitable GPU adapter"; d["millis"] = ms();
+        return d;
+    }
+    vf_device_info di;
+    int rc = vf_device_query(device_ordinal(), &di);
+    if (rc != VF_OK) {
+        d["status"] = "unsupported"; d["message"] = "No suitable GPU adapter"; d["millis"] = ms();
+        return d;
+    }
+    py::dict a = adapter_dict(di);
+    d["adapter_name"] = a["name"];
+    for (const char *k : { "backend", "device_type", "vendor_id", "device_id", "features", "limits" }) d[k] = a[k];
+    vf_ctx *c = nullptr;
+    rc = vf_ctx_create(device_ordinal(), &c);
+    if (rc != VF_OK) {
+        d["status"] = "error"; d["message"] = std::string("request_device failed: ") + vf_last_error(); d["millis"] = ms();
+        return d;
+    }
+    vf_ctx_destroy(c);
+    d["status"] = "ok"; d["millis"] = ms();
+    return d;
+}
+
+template <class T>
+py::class_<T> bind_terrain(py::module_ &m, const char *name)
+{
+    return py::class_<T>(m, name)
+        .def(py::init<uint32_t, uint32_t, py::object, py::object>(), py::arg("width"), py::arg("height"), py::arg("grid") = 128,
+             py::arg("colormap") = "viridis")
+        .def("render_png", &T::render_png, py::arg("path"))
+        .def("render_rgba", &T::render_rgba)
+        .def("set_camera_look_at", &T::set_camera_look_at, py::arg("eye"), py::arg("target"), py::arg("up"), py::arg("fovy_deg"),
+             py::arg("znear"), py::arg("zfar"))
+        .def("debug_uniforms_f32", &T::debug_uniforms_f32)
+        .def("debug_lut_format", &T::debug_lut_format)
+        .def("debug_visibility", &T::debug_visibility)
+        .def("set_shard", &T::set_shard, py::arg("rank"), py::arg("nranks"), py::arg("band_h") = 64)
+        .def("enable_timing", &T::enable_timing, py::arg("on") = true)
+        .def("last_timings", &T::last_timings);
+}
+
+} // namespace
+
+PYBIND11_MODULE(_vulkan_forge, m)
+{
+    m.doc() = "MI355X-native drop-in for vulkan-forge's _vulkan_forge extension (terrain raster hot path)";
+    py::class_<Renderer>(m, "Renderer")
+        .def(py::init<uint32_t, uint32_t>(), py::arg("width"), py::arg("height"))
+        .def("info", &Renderer::info)
+        .def("render_triangle_rgba", &Renderer::render_triangle_rgba)
+        .def("render_triangle_png", &Renderer::render_triangle_png, py::arg("path"));
+    bind_terrain<TerrainSpike>(m, "TerrainSpike");
+    bind_terrain<Scene>(m, "Scene").def("set_height_from_r32f", &Scene::set_height_from_r32f, py::arg("height_r32f"));
+    m.def("enumerate_adapters", &enumerate_adapters);
+    m.def("device_probe", &device_probe, py::arg("backend") = py::none());
+    m.def("grid_generate", &grid_generate, py::arg("nx"), py::arg("nz"), py::arg("spacing") = std::make_tuple(1.0f, 1.0f),
+          py::arg("origin") = "center");
+    m.def("colormap_supported", &colormap_supported);
+    m.def("camera_look_at", &camera_look_at, py::arg("eye"), py::arg("target"), py::arg("up"));
+    m.def("camera_perspective", &camera_perspective, py::arg("fovy_deg"), py::arg("aspect"), py::arg("znear"), py::arg("zfar"),
+          py::arg("clip_space") = "wgpu");
+    m.def("camera_view_proj", &camera_view_proj, py::arg("eye"), py::arg("target"), py::arg("up"), py::arg("fovy_deg"),
+          py::arg("aspect"), py::arg("znear"), py::arg("zfar"), py::arg("clip_space") = "wgpu");
+}
