@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+  metric   Mpix/s terrain shade: W*H*frames / wall time, RGBA8 complete in HBM (rank 0 holds the gathered frame)
+  workload C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
+           (np.random.default_rng(20250816).random(float32)*0.5-0.25), default camera eye (3,2,3), viridis.
+           A "step" = one frame: k_block_ranges + k_tile (+ the band gather to rank 0 when N > 1).
+  N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): the frame is split into 64-row screen
+           bands, band b belongs to rank b % N; every rank renders only its bands, then rank 0 receives each
+           remote band directly into its place in the final image (point-to-point over xGMI).  Total work is
+           fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (fields: see the driver contract; plus "roofline" and "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BAND_H = 64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096, help="frame width = height")
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--camera", choices=["default", "fill"], default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fill camera) measurement")
+    return ap.parse_args()
+
+
+def camera_uniforms(name, W, H):
+    """Uniform block through the product's own host code (the drop-in module), not the oracle."""
+    import vulkan_forge_amd as vf
+    import numpy as np
+    view = vf.camera_look_at((3.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    proj = vf.camera_perspective(45.0, W / H, 0.1, 100.0, "wgpu")
+    if name == "fill":                                           # frame-filling top-down camera
+        view = vf.camera_look_at((0.0, 2.2, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0))
+        proj = vf.camera_perspective(60.0, W / H, 0.1, 100.0, "wgpu")
+    u = np.zeros(44, np.float32)
+    u[:16] = view.T.reshape(-1)                                   # column-major
+    u[16:32] = proj.T.reshape(-1)
+    sun = np.array([0.5, 0.8, 0.6], np.float32)                  # Scene keeps Globals::default (src/terrain/mod.rs:190)
+    u[32:35] = sun * (np.float32(1.0) / np.sqrt(np.float32((sun * sun).sum())))
+    u[35] = 1.0
+    u[36:39] = [1.0, 1.0, 1.0]
+    return u
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch                                                  # first: the HIP runtime it bundles is the one shared below
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vulkan_forge_amd import cabi, dist as vdist
+
+    W = H = args.size
+    G = args.grid
+    lut = np.load(os.path.join(ROOT, "tests", "golden", "colormaps_rgba8.npz"))["viridis"]
+    rng = np.random.default_rng(20250816)
+    height_host = rng.random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+    d_height = torch.from_numpy(height_host).to(dev)              # inputs resident in HBM before the timed region
+
+    t = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)
+    t.set_height_device(d_height.data_ptr(), G, G)
+    t.set_shard(rank, world, BAND_H)
+    rows = t.local_rows()
+    assert rows == vdist.local_rows(H, rank, world, BAND_H)
+    local = torch.empty((rows, W, 4), dtype=torch.uint8, device=dev)
+    image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    t.set_output_device(image.data_ptr() if (world == 1) else local.data_ptr())   # N=1: render straight into the frame
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        t.render(stream)
+        if world > 1:
+            vdist.gather_bands(local, image, H, BAND_H, dst=0)
+
+    def timed(camera, steps, warmup):
+        t.set_uniforms(camera_uniforms(camera, W, H))
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tm = t.timings()
+        t.enable_timing(False)
+        if world > 1:
+            x = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            dt = float(x.item())
+        return dt, tm
+
+    dt, tm = timed(args.camera, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = W * H * args.steps / dt / 1e6
+
+    extra = None
+    if not args.no_extra:
+        other = "fill" if args.camera == "default" else "default"
+        dt2, tm2 = timed(other, max(3, args.steps // 4), 1)
+        n2 = max(3, args.steps // 4)
+        extra = {"camera": other, "value": W * H * n2 / dt2 / 1e6, "ms_per_step": dt2 / n2 * 1e3, "tile_kernel_ms": tm2["tile_ms"]}
+
+    # ---- roofline of the dominant kernel (k_tile: vertex + setup + raster + fragment, fused) -------------------
+    # algorithmic bytes per launch (whole frame): height texture read once + RGBA8 written once + LUT
+    algo_bytes = 4 * G * G + 4 * W * H + 1024
+    share = rows / H                                              # this rank's share of the frame
+    kernel_s = tm["tile_ms"] * 1e-3
+    achieved = (4 * G * G + 4 * W * rows + 1024) / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            key = f"{W}x{H}_g{G}_{args.camera}_n{world}"
+            if key in pm:
+                traffic = pm[key]["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(4 * G * G + 4 * W * rows + 1024), "kernel_ms": tm["tile_ms"],
+                "ranges_kernel_ms": tm["ranges_ms"], "frames_averaged": tm["frames"], "rank_share_of_frame": share}
+
+    # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        threads = max(1, min(os.cpu_count() or 1, 16))
+        u = camera_uniforms(args.camera, W, H)
+        c0 = time.perf_counter()
+        oracle.render_terrain(u, W, H, G, height_host, lut, nthreads=threads, want_vis=False)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+               "sample": f"1 full frame of the same workload ({W}x{H}, grid {G}, {args.camera} camera) in {cdt:.2f} s, "
+                         f"oracle/vf_oracle.c gcc -O2 OpenMP; the reference's wgpu software-adapter path cannot be built in this image"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis",
+                       "width": W, "height": H, "grid": G, "camera": args.camera,
+                       "parallelism": f"screen bands of {BAND_H} rows, round-robin over {world} GPU(s)" + (", p2p gather to rank 0 (RCCL)" if world > 1 else "")},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "other_camera": extra,
+        }
+        print(json.dumps(out), flush=True)
+    t.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,14 +51,15 @@ typedef struct vf_device_info {
     int32_t pci_device_id;
 } vf_device_info;
 
-/* per-kernel device time of the LAST vf_terrain_render with timing enabled (HIP events on the render stream) */
+/* per-kernel device time (HIP events on the render stream), averaged over the frames rendered since
+ * vf_terrain_enable_timing(t, 1) -- at most the last 64 */
 typedef struct vf_timings {
-    float geometry_ms;  /* fused vertex + triangle setup + small-triangle raster kernel */
-    float generic_ms;   /* clipped / large-triangle raster kernel */
-    float resolve_ms;   /* fragment (visibility -> RGBA8) kernel */
+    float ranges_ms;    /* k_block_ranges: per-block screen-tile rectangles */
+    float tile_ms;      /* k_tile: vertex + setup + LDS raster + fragment stage, one workgroup per screen tile */
     float total_ms;     /* first launch -> RGBA8 complete */
-    uint32_t generic_prims; /* primitives routed to the generic kernel */
-    uint32_t culled_blocks; /* grid blocks rejected by the screen/shard bound test */
+    uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out) */
+    uint32_t tiles;             /* workgroups launched = owned screen tiles */
+    uint32_t frames;            /* frames averaged */
 } vf_timings;
 
 const char *vf_last_error(void);

@@ -66,6 +66,7 @@ def _load() -> C.CDLL:
     lib.vfo_render_terrain.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, C.c_uint32, C.c_uint32,
                                        _u8p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u32p, C.c_int]
     lib.vfo_render_triangle.argtypes = [C.c_uint32, C.c_uint32, _u8p]
+    lib.vfo_raster_triangles.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
     return lib
 
 
@@ -194,19 +195,28 @@ def render_terrain(u, W, H, grid, height, lut_rgba8, lut_is_srgb=True, rank=0, n
     assert height.ndim == 2
     lut = np.ascontiguousarray(lut_rgba8, dtype=np.uint8).reshape(1024)
     rgba = np.empty((H, W, 4), np.uint8)
-    vis = np.empty((H, W), np.uint32) if want_vis else None
+    vis = np.empty((H, W), np.uint32)
     rc = lib().vfo_render_terrain(_p(u, _f32p), W, H, grid, _p(height, _f32p), height.shape[1], height.shape[0],
                                   _p(lut, _u8p), int(bool(lut_is_srgb)), rank, nranks, band_h,
-                                  _p(rgba, _u8p), _p(vis, _u32p) if want_vis else None, int(nthreads))
+                                  _p(rgba, _u8p), _p(vis, _u32p), int(nthreads))
     if rc != 0:
         raise MemoryError("oracle allocation failed")
-    return rgba, vis
+    return rgba, (vis if want_vis else None)
 
 
 def render_triangle(W, H):
     rgba = np.empty((H, W, 4), np.uint8)
     lib().vfo_render_triangle(W, H, _p(rgba, _u8p))
     return rgba
+
+
+def raster_triangles(clip_xyzw, W, H):
+    """clip_xyzw: (ntris, 3, 4) float32 clip-space vertices -> (H, W) u32 surviving primitive id + 1."""
+    v = np.ascontiguousarray(clip_xyzw, dtype=np.float32).reshape(-1, 3, 4)
+    vis = np.empty((H, W), np.uint32)
+    if lib().vfo_raster_triangles(_p(v, _f32p), v.shape[0], W, H, _p(vis, _u32p)) != 0:
+        raise MemoryError("oracle allocation failed")
+    return vis
 
 
 def max_threads():

@@ -399,8 +399,11 @@ typedef struct { int32_t X, Y; float rw; float a[3]; } svert;      /* snapped sc
 typedef struct {
     uint32_t W, H;
     uint8_t *rgba;        /* W*H*4 */
-    uint32_t *vis;        /* W*H  (prim+1; 0 = background) or NULL */
-    uint64_t *key;        /* W*H  ((prim+1)<<32 | rgba) used by the multi-thread path, or NULL */
+    uint32_t *vis;        /* W*H  (prim+1; 0 = background) */
+    int pass;             /* 0: visibility pass (which primitive's fragment survives at each pixel)
+                             1: fragment pass (evaluate fs_main for the surviving fragment only) */
+    int atomic_vis;       /* visibility pass runs on several threads: merge with an atomic max */
+    int32_t sc_x0, sc_x1, sc_y0, sc_y1;   /* inclusive scissor (fragment pass: the one pixel being shaded) */
     /* row ownership (multi-GPU band split, DESIGN.md "Sharding"): pixel row y is rendered iff
        ((y / band_h) % nranks) == rank.  nranks == 1 -> every row. */
     uint32_t rank, nranks, band_h;
@@ -454,19 +457,19 @@ static inline int row_owned(const rtarget *rt, int y)
     return rt->nranks <= 1 || (((uint32_t)y / rt->band_h) % rt->nranks) == rt->rank;
 }
 
-static inline void store_fragment(const rtarget *rt, int px, int py, uint32_t prim, const uint8_t c[4])
+/* Painter's order without depth or blending: fragments reach a pixel in primitive order and the
+ * last one survives.  fs_main has no side effects, so only the survivor's colour is observable:
+ * pass 0 records which primitive survives (a later primitive simply overwrites; with several
+ * threads "later" = larger id, merged by atomic max), pass 1 re-draws that primitive under a
+ * one-pixel scissor with the very same code and evaluates fs_main for its fragment. */
+static inline void store_visibility(const rtarget *rt, int px, int py, uint32_t prim)
 {
     size_t o = (size_t)py * rt->W + px;
-    if (rt->key) {
-        /* multi-thread path: last-writer-wins in API order == max over (prim) keys */
-        uint32_t packed; memcpy(&packed, c, 4);
-        uint64_t k = ((uint64_t)(prim + 1) << 32) | packed;
-        uint64_t cur = __atomic_load_n(&rt->key[o], __ATOMIC_RELAXED);
-        while (k > cur && !__atomic_compare_exchange_n(&rt->key[o], &cur, k, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    if (rt->atomic_vis) {
+        uint32_t k = prim + 1, cur = __atomic_load_n(&rt->vis[o], __ATOMIC_RELAXED);
+        while (k > cur && !__atomic_compare_exchange_n(&rt->vis[o], &cur, k, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     } else {
-        /* painter's order: primitives arrive in index order, the later one simply overwrites */
-        memcpy(rt->rgba + 4 * o, c, 4);
-        if (rt->vis) rt->vis[o] = prim + 1;
+        rt->vis[o] = prim + 1;
     }
 }
 
@@ -506,6 +509,10 @@ static void raster_triangle(const rtarget *rt, frag_fn fs, const cvert v[3], uin
     px0 = px0 < 0 ? 0 : px0; py0 = py0 < 0 ? 0 : py0;
     if (px1 > (int32_t)rt->W - 1) px1 = (int32_t)rt->W - 1;
     if (py1 > (int32_t)rt->H - 1) py1 = (int32_t)rt->H - 1;
+    if (px0 < rt->sc_x0) px0 = rt->sc_x0;
+    if (py0 < rt->sc_y0) py0 = rt->sc_y0;
+    if (px1 > rt->sc_x1) px1 = rt->sc_x1;
+    if (py1 > rt->sc_y1) py1 = rt->sc_y1;
     if (px0 > px1 || py0 > py1) return;
     const float fA = (float)(-area2);
     /* inside-positive edge weights e_i = -E_{jk}(P); top-left rule on their gradients */
@@ -526,15 +533,14 @@ static void raster_triangle(const rtarget *rt, frag_fn fs, const cvert v[3], uin
             if (!(e0 > 0 || (e0 == 0 && tl0))) continue;
             if (!(e1 > 0 || (e1 == 0 && tl1))) continue;
             if (!(e2 > 0 || (e2 == 0 && tl2))) continue;
+            if (rt->pass == 0) { store_visibility(rt, px, py, prim); continue; }
             float l0 = (float)e0 / fA, l1 = (float)e1 / fA, l2 = (float)e2 / fA;
             float q0 = l0 * s[0].rw, q1 = l1 * s[1].rw, q2 = l2 * s[2].rw;
             float rQ = 1.0f / ((q0 + q1) + q2);
             float attr[3];
             for (int k = 0; k < 3; ++k)
                 attr[k] = fmaf(q2, s[2].a[k], fmaf(q1, s[1].a[k], q0 * s[0].a[k])) * rQ;
-            uint8_t c[4];
-            fs(rt, attr, c);
-            store_fragment(rt, px, py, prim, c);
+            fs(rt, attr, rt->rgba + 4 * ((size_t)py * rt->W + px));
         }
     }
 }
@@ -622,39 +628,39 @@ static void vs_terrain(const vsctx *c, uint32_t i, uint32_t j, cvert *o)
     o->a[0] = h; o->a[1] = x; o->a[2] = z;                                 /* height, xz :63-64 (uv unused by fs) */
 }
 
-static void setup_target(rtarget *rt, uint32_t W, uint32_t H, uint8_t *rgba, uint32_t *vis, uint64_t *key,
+static void setup_target(rtarget *rt, uint32_t W, uint32_t H, uint8_t *rgba, uint32_t *vis,
                          uint32_t rank, uint32_t nranks, uint32_t band_h)
 {
     memset(rt, 0, sizeof *rt);
-    rt->W = W; rt->H = H; rt->rgba = rgba; rt->vis = vis; rt->key = key;
+    rt->W = W; rt->H = H; rt->rgba = rgba; rt->vis = vis;
     rt->rank = rank; rt->nranks = nranks ? nranks : 1; rt->band_h = band_h ? band_h : 1;
+    rt->sc_x0 = 0; rt->sc_y0 = 0; rt->sc_x1 = (int32_t)W - 1; rt->sc_y1 = (int32_t)H - 1;
 }
 static void clear_target(const rtarget *rt, const float clear_linear[3])
 {
     uint8_t c[4] = { srgb_encode(clear_linear[0]), srgb_encode(clear_linear[1]), srgb_encode(clear_linear[2]), 255 };
     size_t npx = (size_t)rt->W * rt->H;
-    uint32_t packed; memcpy(&packed, c, 4);
     for (size_t o = 0; o < npx; ++o) {
         memcpy(rt->rgba + 4 * o, c, 4);
-        if (rt->vis) rt->vis[o] = 0;
-        if (rt->key) rt->key[o] = packed;
+        rt->vis[o] = 0;
     }
 }
-static void resolve_keys(const rtarget *rt)
+
+/* primitive id -> its three grid vertices in index order [a,c,b, b,c,d] (src/terrain/mod.rs:578-582) */
+static void terrain_prim(const vsctx *vc, uint32_t prim, cvert t[3])
 {
-    size_t npx = (size_t)rt->W * rt->H;
-    for (size_t o = 0; o < npx; ++o) {
-        uint32_t packed = (uint32_t)rt->key[o];
-        memcpy(rt->rgba + 4 * o, &packed, 4);
-        if (rt->vis) rt->vis[o] = (uint32_t)(rt->key[o] >> 32);
-    }
+    uint32_t nm1 = vc->n - 1, cell = prim >> 1, j = cell / nm1, i = cell - j * nm1;
+    if ((prim & 1u) == 0) { vs_terrain(vc, i, j, &t[0]); vs_terrain(vc, i, j + 1, &t[1]); vs_terrain(vc, i + 1, j, &t[2]); }
+    else { vs_terrain(vc, i + 1, j, &t[0]); vs_terrain(vc, i, j + 1, &t[1]); vs_terrain(vc, i + 1, j + 1, &t[2]); }
 }
 
 /*
  * Full terrain frame = render_png's render pass (src/terrain/mod.rs:412-437 / src/scene/mod.rs:280-298)
- * up to the RGBA8 texture contents.  `height` NULL -> caller did not upload: pass the class's dummy.
- * rows not owned by (rank,nranks,band_h) keep the clear colour.
- * nthreads <= 1: literal painter's loop.  nthreads > 1: OpenMP over grid rows, (prim,colour) max-merge.
+ * up to the RGBA8 texture contents.  `height`: the bound R32F texture (the class's dummy when the
+ * caller never uploaded one).  Rows not owned by (rank,nranks,band_h) keep the clear colour.
+ * nthreads <= 1: primitives are drawn strictly in index order on one thread (literal painter's loop);
+ * nthreads > 1: grid rows are spread over OpenMP threads and merged by max primitive id.
+ * vis (W*H u32, required): surviving primitive id + 1 per pixel, 0 = background.
  * Returns 0, or -1 on allocation failure.
  */
 VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32_t grid,
@@ -665,13 +671,9 @@ VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32
 {
     init_tables();
     uint32_t n = grid < 2 ? 2 : grid;
+    if (nthreads < 1) nthreads = 1;
     rtarget rt;
-    uint64_t *key = NULL;
-    if (nthreads > 1) {
-        key = (uint64_t *)malloc((size_t)W * H * sizeof(uint64_t));
-        if (!key) return -1;
-    }
-    setup_target(&rt, W, H, rgba, vis, key, rank, nranks, band_h);
+    setup_target(&rt, W, H, rgba, vis, rank, nranks, band_h);
     rt.mode = 0;
     rt.h_range = fmaxf(u[37], 1e-8f);                                    /* terrain.wgsl:71 */
     rt.exposure = u[35];
@@ -692,9 +694,12 @@ VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32
     vc.exag = u[38];
     vc.step = (2.0f * 1.5f) / ((float)n - 1.0f);                          /* src/terrain/mod.rs:559-560 */
 
+    /* ---- pass 0: which primitive's fragment survives at each pixel ---- */
+    rt.pass = 0;
+    rt.atomic_vis = nthreads > 1;
     int fail = 0;
 #ifdef _OPENMP
-#pragma omp parallel num_threads(nthreads > 1 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads)
 #endif
     {
         cvert *row0 = (cvert *)malloc((size_t)n * sizeof(cvert));
@@ -726,8 +731,25 @@ VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32
         }
         free(row0); free(row1);
     }
-    if (key) { resolve_keys(&rt); free(key); }
-    return fail ? -1 : 0;
+    if (fail) return -1;
+
+    /* ---- pass 1: fs_main for the surviving fragment of every covered pixel ---- */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (long py = 0; py < (long)H; ++py) {
+        rtarget r1 = rt;
+        r1.pass = 1; r1.atomic_vis = 0;
+        for (uint32_t px = 0; px < W; ++px) {
+            uint32_t id = vis[(size_t)py * W + px];
+            if (!id) continue;
+            cvert t[3];
+            terrain_prim(&vc, id - 1, t);
+            r1.sc_x0 = r1.sc_x1 = (int32_t)px; r1.sc_y0 = r1.sc_y1 = (int32_t)py;
+            draw_primitive(&r1, frag_terrain, t, id - 1);
+        }
+    }
+    return 0;
 }
 
 /* Triangle smoke path: src/lib.rs:72-91 (geometry), :685-721 (pass; clear WHITE :19),
@@ -735,8 +757,10 @@ VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32
 VFO_API int vfo_render_triangle(uint32_t W, uint32_t H, uint8_t *rgba)
 {
     init_tables();
+    uint32_t *vis = (uint32_t *)malloc((size_t)W * H * sizeof(uint32_t));
+    if (!vis) return -1;
     rtarget rt;
-    setup_target(&rt, W, H, rgba, NULL, NULL, 0, 1, 1);
+    setup_target(&rt, W, H, rgba, vis, 0, 1, 1);
     rt.mode = 1;
     const float clear[3] = { 1.0f, 1.0f, 1.0f };
     clear_target(&rt, clear);
@@ -745,7 +769,34 @@ VFO_API int vfo_render_triangle(uint32_t W, uint32_t H, uint8_t *rgba)
         { 0.8f, -0.8f, 0.0f, 1.0f, { 0.2f, 1.0f, 0.2f } },
         { 0.0f, 0.8f, 0.0f, 1.0f, { 0.2f, 0.2f, 1.0f } },
     };
-    draw_primitive(&rt, frag_triangle, v, 0);
+    rt.pass = 0; draw_primitive(&rt, frag_triangle, v, 0);
+    rt.pass = 1; draw_primitive(&rt, frag_triangle, v, 0);   /* one primitive: every covered pixel is its own */
+    free(vis);
+    return 0;
+}
+
+/* Convention test hook: rasterise arbitrary clip-space triangles (xyzw per vertex) in index order and
+ * return the surviving primitive id + 1 per pixel -- exercises the fill rule, culling and clipping. */
+VFO_API int vfo_raster_triangles(const float *clip_xyzw, uint32_t ntris, uint32_t W, uint32_t H, uint32_t *vis)
+{
+    init_tables();
+    uint8_t *rgba = (uint8_t *)malloc((size_t)W * H * 4);
+    if (!rgba) return -1;
+    rtarget rt;
+    setup_target(&rt, W, H, rgba, vis, 0, 1, 1);
+    const float clear[3] = { 0.0f, 0.0f, 0.0f };
+    clear_target(&rt, clear);
+    rt.pass = 0;
+    for (uint32_t t = 0; t < ntris; ++t) {
+        cvert v[3];
+        for (int k = 0; k < 3; ++k) {
+            const float *p = clip_xyzw + (size_t)(3 * t + k) * 4;
+            v[k].x = p[0]; v[k].y = p[1]; v[k].z = p[2]; v[k].w = p[3];
+            v[k].a[0] = v[k].a[1] = v[k].a[2] = 0.0f;
+        }
+        draw_primitive(&rt, frag_triangle, v, t);
+    }
+    free(rgba);
     return 0;
 }
 

@@ -1,0 +1,134 @@
+"""The reference's own integration tests, re-expressed against the drop-in module (needs the GPU):
+tests/test_t31_integration.py, test_t41_scene.py, test_colormap.py, test_determinism.py, test_api.py,
+test_api_validation.py, test_camera.py::TestTerrainSpikeIntegration."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import vulkan_forge as vfpkg                      # noqa: E402
+import vulkan_forge._vulkan_forge as vf           # noqa: E402
+
+
+def test_t31_uniform_lanes_layout():
+    spike = vf.TerrainSpike(256, 192, grid=64, colormap="viridis")
+    u = spike.debug_uniforms_f32()
+    assert isinstance(u, np.ndarray) and u.dtype == np.float32 and u.shape == (44,)
+    assert abs(u[36] - 1) < 1e-6 and abs(u[37] - 1) < 1e-6 and abs(u[38] - 1) < 1e-6 and abs(u[39]) < 1e-6
+
+
+def test_t31_render_png_smoke(tmp_path):
+    out = tmp_path / "terrain_smoke.png"
+    vf.TerrainSpike(320, 240, grid=64, colormap="viridis").render_png(str(out))
+    assert out.exists() and out.stat().st_size > 4096
+
+
+def test_t41_scene_renders_png_and_height_upload_changes_output(tmp_path):
+    from PIL import Image
+    o1, o2 = tmp_path / "s1.png", tmp_path / "s2.png"
+    scn = vf.Scene(320, 240, grid=64, colormap="viridis")
+    scn.render_png(str(o1))
+    assert o1.stat().st_size > 4096
+    h = (np.sin(np.linspace(0, 4 * np.pi, 128))[:, None] * np.cos(np.linspace(0, 4 * np.pi, 128))[None, :]).astype("float32") * 0.25
+    scn.set_height_from_r32f(h)
+    scn.render_png(str(o2))
+    assert o1.stat().st_size != o2.stat().st_size
+    a, b = np.asarray(Image.open(o1)), np.asarray(Image.open(o2))
+    assert a.shape == (240, 320, 4) and not np.array_equal(a, b)
+
+
+def test_png_holds_exactly_the_rendered_pixels(tmp_path, oracle, luts):
+    from PIL import Image
+    W, H, G = 200, 120, 32
+    out = tmp_path / "p.png"
+    s = vf.TerrainSpike(W, H, grid=G, colormap="magma")
+    s.render_png(str(out))
+    png = np.asarray(Image.open(out).convert("RGBA"))
+    ref, _ = oracle.render_terrain(oracle.default_uniforms(0, W, H), W, H, G, oracle.SPIKE_DUMMY_HEIGHT, luts["magma"])
+    assert np.array_equal(png, s.render_rgba())
+    assert np.abs(png.astype(int) - ref.astype(int)).max() <= 1
+
+
+def test_height_argument_errors():
+    scn = vf.Scene(64, 64, grid=8)
+    with pytest.raises(RuntimeError, match="height must be C-contiguous"):
+        scn.set_height_from_r32f(np.zeros((8, 16), np.float32)[:, ::2])
+    with pytest.raises(TypeError):
+        scn.set_height_from_r32f(np.zeros((8, 8), np.float64))
+    with pytest.raises(TypeError):
+        scn.set_height_from_r32f(np.zeros(8, np.float32))
+    with pytest.raises(TypeError):
+        scn.set_height_from_r32f([[0.0, 1.0]])
+    assert not hasattr(vf.TerrainSpike(64, 64, grid=8), "set_height_from_r32f")   # TerrainSpike has no height setter
+
+
+def test_camera_integration():
+    spike = vf.TerrainSpike(512, 512)
+    u0 = spike.debug_uniforms_f32()
+    assert len(u0) == 44
+    spike.set_camera_look_at((1.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 60.0, 0.1, 100.0)
+    assert not np.allclose(u0, spike.debug_uniforms_f32())
+    with pytest.raises(RuntimeError, match=r"fovy_deg must be finite and in \(0, 180\)"):
+        spike.set_camera_look_at((0, 0, 3), (0, 0, 0), (0, 1, 0), 0.0, 0.1, 100.0)
+    with pytest.raises(RuntimeError, match="up vector must not be colinear"):
+        spike.set_camera_look_at((0, 0, 3), (0, 0, 0), (0, 0, -1), 45.0, 0.1, 100.0)
+    spike.set_camera_look_at((0, 0, 3), (0, 0, 0), (0, 1, 0), 45.0, 0.1, 100.0)
+    u = spike.debug_uniforms_f32()
+    np.testing.assert_allclose(u[:16].reshape(4, 4, order="F"), vf.camera_look_at((0, 0, 3), (0, 0, 0), (0, 1, 0)), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(u[16:32].reshape(4, 4, order="F"), vf.camera_perspective(45.0, 1.0, 0.1, 100.0, "wgpu"), rtol=1e-5, atol=1e-6)
+    t = vf.TerrainSpike(128, 96, grid=32)
+    proj = t.debug_uniforms_f32()[16:32].reshape(4, 4, order="F")
+    assert np.allclose(proj, vf.camera_perspective(45.0, 128 / 96, 0.1, 100.0, clip_space="wgpu"), atol=1e-6)
+
+
+def test_colormaps_render_and_format_selection(tmp_path, monkeypatch):
+    for cm in ("viridis", "magma", "terrain"):
+        out = tmp_path / f"{cm}.png"
+        vf.TerrainSpike(128, 128, grid=32, colormap=cm).render_png(str(out))
+        assert out.stat().st_size > 1000
+    assert vf.TerrainSpike(128, 128, grid=32).debug_lut_format() in ("Rgba8UnormSrgb", "Rgba8Unorm")
+    monkeypatch.setenv("VF_FORCE_LUT_UNORM", "1")
+    t = vf.TerrainSpike(128, 128, grid=32, colormap="viridis")
+    assert t.debug_lut_format() == "Rgba8Unorm"
+    out = tmp_path / "unorm.png"
+    t.render_png(str(out))
+    assert out.stat().st_size > 1000
+
+
+def test_unorm_fallback_matches_oracle(monkeypatch, oracle, luts):
+    monkeypatch.setenv("VF_FORCE_LUT_UNORM", "1")
+    W, H, G = 160, 120, 32
+    t = vf.Scene(W, H, grid=G, colormap="terrain")
+    ref, _ = oracle.render_terrain(oracle.default_uniforms(1, W, H), W, H, G, oracle.SCENE_DUMMY_HEIGHT,
+                                   oracle.lut_to_linear_u8(luts["terrain"]), lut_is_srgb=False)
+    assert np.abs(t.render_rgba().astype(int) - ref.astype(int)).max() <= 1
+
+
+def test_triangle_determinism_and_api(tmp_path):
+    shas = set()
+    for _ in range(3):
+        a = vfpkg.Renderer(64, 64).render_triangle_rgba()
+        assert a.shape == (64, 64, 4) and a.dtype == np.uint8
+        shas.add(hashlib.sha256(a.tobytes()).hexdigest())
+    assert len(shas) == 1
+    assert vfpkg.Renderer(16, 16).info() == "Renderer 16x16, format=Rgba8UnormSrgb"
+    a = vfpkg.render_triangle_rgba(32, 24)
+    assert a.shape == (24, 32, 4)
+    out = tmp_path / "tri.png"
+    vfpkg.render_triangle_png(str(out), 32, 24)
+    assert out.exists() and out.stat().st_size > 0
+    t = vfpkg.make_terrain(64, 48, 16)
+    o2 = tmp_path / "t.png"
+    t.render_png(str(o2))
+    assert o2.exists() and o2.stat().st_size > 0
+
+
+def test_diagnostics():
+    ads = vf.enumerate_adapters()
+    assert ads and ads[0]["backend"] == "HIP" and "gfx" in ads[0]["features"]
+    p = vf.device_probe()
+    assert p["status"] == "ok" and p["millis"] >= 0 and p["backend_request"] == "AUTO"
+    assert vf.device_probe("vulkan")["status"] == "unsupported"

@@ -47,7 +47,8 @@ def render_triangle_rgba(width: int, height: int):
 def render_triangle_png(path, width: int, height: int) -> None:
     """Deterministic triangle written as PNG (reference shim :60-64)."""
     w, h = size_wh(width, height)
-    Renderer(w, h).render_triangle_png(png_path(path))
+    out = png_path(path)          # argument errors first: they must not depend on a device being present
+    Renderer(w, h).render_triangle_png(out)
 
 
 def make_terrain(width: int, height: int, grid: int = 128):

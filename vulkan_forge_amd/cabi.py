@@ -1,0 +1,158 @@
+"""ctypes view of the C-ABI (include/vf_hip.h) -- for callers that own device memory and streams
+(bench.py, the torch.distributed shard driver, the C-ABI tests).  The drop-in Python classes live in
+the compiled `_vulkan_forge` module; this file only declares the same entry points for ctypes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libvf_hip.so")
+
+VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -3, -4
+
+# every symbol include/vf_hip.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info",
+    "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
+    "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_output_device",
+    "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
+    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
+    "vf_stitch_bands_device",
+]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 256), ("arch", C.c_char * 64), ("device_ordinal", C.c_int32), ("compute_units", C.c_int32),
+                ("wavefront_size", C.c_int32), ("clock_khz", C.c_int32), ("total_mem_bytes", C.c_uint64),
+                ("lds_bytes_per_cu", C.c_uint64), ("pci_bus_id", C.c_int32), ("pci_device_id", C.c_int32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ranges_ms", C.c_float), ("tile_ms", C.c_float), ("total_ms", C.c_float),
+                ("blocks_rasterised", C.c_uint32), ("tiles", C.c_uint32), ("frames", C.c_uint32)]
+
+
+_vp, _u32, _f, _i = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+_PROTOS = {
+    "vf_last_error": (C.c_char_p, []),
+    "vf_device_count": (_i, [C.POINTER(_i)]),
+    "vf_device_query": (_i, [_i, C.POINTER(DeviceInfo)]),
+    "vf_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "vf_ctx_destroy": (None, [_vp]),
+    "vf_ctx_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
+    "vf_terrain_create": (_i, [_vp, _u32, _u32, _u32, _vp, _i, C.POINTER(_vp)]),
+    "vf_terrain_destroy": (None, [_vp]),
+    "vf_terrain_set_uniforms": (_i, [_vp, _vp]),
+    "vf_terrain_set_height": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_terrain_set_height_device": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_terrain_set_shard": (_i, [_vp, _u32, _u32, _u32]),
+    "vf_terrain_local_rows": (_i, [_vp, C.POINTER(_u32)]),
+    "vf_terrain_set_output_device": (_i, [_vp, _vp]),
+    "vf_terrain_rgba_device": (_i, [_vp, C.POINTER(_vp)]),
+    "vf_terrain_render": (_i, [_vp, _vp]),
+    "vf_terrain_sync": (_i, [_vp]),
+    "vf_terrain_read_rgba": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_terrain_read_visibility": (_i, [_vp, _vp]),
+    "vf_terrain_enable_timing": (_i, [_vp, _i]),
+    "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
+    "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
+    "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
+    "vf_stitch_bands_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+}
+
+
+def load(path: str = DEFAULT_LIB) -> C.CDLL:
+    """dlopen the library and attach prototypes.  Raises OSError when it is missing: there is no fallback."""
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+class VfError(RuntimeError):
+    pass
+
+
+class Terrain:
+    """Thin RAII wrapper over vf_ctx + vf_terrain for callers that pass raw device pointers / streams."""
+
+    def __init__(self, width, height, grid, lut_rgba8, lut_is_srgb=True, device=0, lib=None):
+        self.lib = lib or load()
+        self.W, self.H, self.grid = int(width), int(height), int(grid)
+        self.ctx, self.t = _vp(), _vp()
+        self._check(self.lib.vf_ctx_create(int(device), C.byref(self.ctx)))
+        lut = np.ascontiguousarray(lut_rgba8, dtype=np.uint8).reshape(1024)
+        self._check(self.lib.vf_terrain_create(self.ctx, self.W, self.H, self.grid, lut.ctypes.data, int(bool(lut_is_srgb)),
+                                               C.byref(self.t)))
+
+    def _check(self, rc):
+        if rc != VF_OK:
+            msg = self.lib.vf_last_error().decode()
+            raise VfError("No suitable GPU adapter" if rc == VF_ERR_NO_DEVICE else msg)
+
+    def close(self):
+        if self.t:
+            self.lib.vf_terrain_destroy(self.t)
+            self.t = _vp()
+        if self.ctx:
+            self.lib.vf_ctx_destroy(self.ctx)
+            self.ctx = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def set_uniforms(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(44)
+        self._check(self.lib.vf_terrain_set_uniforms(self.t, u.ctypes.data))
+
+    def set_height(self, h):
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        self._check(self.lib.vf_terrain_set_height(self.t, h.ctypes.data, h.shape[1], h.shape[0]))
+
+    def set_height_device(self, dptr, tw, th):
+        self._check(self.lib.vf_terrain_set_height_device(self.t, _vp(dptr), tw, th))
+
+    def set_shard(self, rank, nranks, band_h=64):
+        self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))
+
+    def local_rows(self):
+        r = _u32()
+        self._check(self.lib.vf_terrain_local_rows(self.t, C.byref(r)))
+        return r.value
+
+    def set_output_device(self, dptr):
+        self._check(self.lib.vf_terrain_set_output_device(self.t, _vp(dptr)))
+
+    def render(self, stream=None):
+        self._check(self.lib.vf_terrain_render(self.t, _vp(stream or 0)))
+
+    def sync(self):
+        self._check(self.lib.vf_terrain_sync(self.t))
+
+    def read_rgba(self):
+        rows = self.local_rows()
+        out = np.empty((rows, self.W, 4), np.uint8)
+        self._check(self.lib.vf_terrain_read_rgba(self.t, out.ctypes.data, 0, rows))
+        return out
+
+    def read_visibility(self):
+        out = np.empty((self.local_rows(), self.W), np.uint32)
+        self._check(self.lib.vf_terrain_read_visibility(self.t, out.ctypes.data))
+        return out
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.vf_terrain_enable_timing(self.t, int(on)))
+
+    def timings(self):
+        tm = Timings()
+        self._check(self.lib.vf_terrain_timings(self.t, C.byref(tm)))
+        return {k: getattr(tm, k) for k, _ in Timings._fields_}

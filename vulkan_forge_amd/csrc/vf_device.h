@@ -12,16 +12,13 @@
 namespace vf {
 
 // ---- constants shared by the kernels -------------------------------------------------------
-constexpr int kBlockCells = 32;                 // grid block = 32 x 32 cells
-constexpr int kBlockVerts = kBlockCells + 1;    // 33 x 33 vertices incl. shared edge
-constexpr int kGeomThreads = 256;
-constexpr uint32_t kTagShift = 25;              // vis word = tag(7) | prim+1 (25)
-constexpr uint32_t kPrimMask = (1u << kTagShift) - 1u;
-constexpr int kSmallExtent = 1 << 14;           // fast path: triangle extent < 64 px (fixed point 24.8)
-constexpr int kSmallPixels = 64;                // fast path: pixel-centre bbox <= 64 candidates
-constexpr int kGenericSplit = 16;               // generic kernel: row-interleaved parts per primitive
+constexpr int kBlockCells = 16;                 // grid block = 16 x 16 cells (512 primitives)
+constexpr int kBlockVerts = kBlockCells + 1;    // 17 x 17 vertices incl. the shared edges
+constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (64*64*4 B = 16 KiB)
+constexpr int kTileThreads = 256;
+constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 
-constexpr uint32_t F_NEAR = 1u, F_FAR = 2u, F_BAD = 4u;
+constexpr uint32_t F_NEAR = 1u, F_FAR = 2u, F_BAD = 4u, F_NOSNAP = 8u;
 
 struct FrameParams {
     float view[16];
@@ -31,14 +28,17 @@ struct FrameParams {
     float Lx, Ly, Lz;               // normalize(sun)                   (terrain.wgsl:83)
     float hw, hh;                   // 0.5*W, 0.5*H
     uint32_t n, nm1;                // grid vertices per side, cells per side
+    uint32_t nb;                    // blocks per side = ceil(nm1 / kBlockCells)
     uint32_t W, H;
+    uint32_t ntx, nty;              // screen tiles per row / column
     uint32_t tw, th;
     uint32_t rank, nranks, band_shift, band_h;
     uint32_t local_rows;
-    uint32_t tag;                   // current frame tag << kTagShift (0 when tags are disabled)
     uint32_t clear_rgba;            // packed sRGB8 clear colour
-    uint32_t slow_cap;
 };
+
+// inclusive tile rectangle a grid block (or a whole block row) may touch; x0 > x1 = empty
+struct TileRange { uint16_t x0, y0, x1, y1; };
 
 // ---- deterministic sin / cos ---------------------------------------------------------------
 __device__ __forceinline__ float sin_poly(float r)

@@ -73,12 +73,10 @@ struct vf_ctx {
 struct vf_terrain {
     vf_ctx *ctx = nullptr;
     uint32_t W = 0, H = 0, n = 0;
-    uint32_t nbx = 0, nblocks = 0;
-    uint64_t nprims = 0;
-    bool use_tags = true;
-    uint32_t frame = 0;           // frames rendered since the last visibility clear
+    uint32_t nb = 0, nblocks = 0;        // 16x16-cell blocks per side / in total
+    uint32_t ntx = 0, nty = 0;           // 64x64 screen tiles
     // shard
-    uint32_t rank = 0, nranks = 1, band_h = 64, local_rows = 0;
+    uint32_t rank = 0, nranks = 1, band_h = kTileH, local_rows = 0;
     // uniforms
     float u[44];
     bool have_uniforms = false;
@@ -89,18 +87,19 @@ struct vf_terrain {
     const float *d_height = nullptr;
     uint32_t tw = 1, th = 1;
     bool bounds_dirty = true;
-    float2 *d_bounds = nullptr;
-    float *d_lut = nullptr;       // 256*3 linear floats
-    uint32_t *d_vis = nullptr;
+    float2 *d_bounds = nullptr;          // per block: min/max displaced height
+    TileRange *d_ranges = nullptr;       // per block: tile rectangle (per frame)
+    TileRange *d_row_ranges = nullptr;   // per block row
+    float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint32_t *d_rgba = nullptr;
-    uint32_t *d_slow = nullptr;
-    uint32_t *d_counters = nullptr;   // [0] slow count, [1] culled blocks, [2],[3] last frame's copies
-    uint32_t *d_scratch = nullptr;    // decode target for read_visibility
-    size_t vis_capacity_px = 0;
-    // timing
+    uint32_t *d_vis = nullptr;           // only allocated for vf_terrain_read_visibility
+    uint32_t *d_stats = nullptr;         // [0] (tile, block) pairs rasterised
+    // timing: a ring of (start, after ranges, after tile) event triplets, one per rendered frame
+    static constexpr int kTimingRing = 64;
     bool timing = false;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[kTimingRing][3] = {};
+    uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
     bool rendered = false;
 };
@@ -199,20 +198,6 @@ static uint32_t compute_local_rows(uint32_t H, uint32_t rank, uint32_t nranks, u
     return rows;
 }
 
-static int alloc_targets(vf_terrain *t)
-{
-    // the largest per-rank share any shard setting can produce is the full frame; allocate once for it
-    size_t npx = (size_t)t->W * t->H;
-    if (npx <= t->vis_capacity_px) return VF_OK;
-    VF_HIP_TRY(hipMalloc(&t->d_vis, npx * sizeof(uint32_t)));
-    VF_HIP_TRY(hipMalloc(&t->d_rgba_own, npx * sizeof(uint32_t)));
-    VF_HIP_TRY(hipMalloc(&t->d_scratch, npx * sizeof(uint32_t)));
-    VF_HIP_TRY(hipMemset(t->d_vis, 0, npx * sizeof(uint32_t)));
-    t->vis_capacity_px = npx;
-    if (!t->d_rgba) t->d_rgba = t->d_rgba_own;
-    return VF_OK;
-}
-
 static AxisTables axis(const vf_terrain *t)
 {
     AxisTables A;
@@ -241,10 +226,10 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     vf_terrain *t = new (std::nothrow) vf_terrain;
     if (!t) return fail(VF_ERR_NOMEM, "out of host memory");
     t->ctx = ctx; t->W = width; t->H = height; t->n = n;
-    t->nbx = (n - 1 + kBlockCells - 1) / kBlockCells;
-    t->nblocks = t->nbx * t->nbx;
-    t->nprims = 2ull * (n - 1) * (n - 1);
-    t->use_tags = t->nprims < (1ull << kTagShift);
+    t->nb = (n - 1 + kBlockCells - 1) / kBlockCells;
+    t->nblocks = t->nb * t->nb;
+    t->ntx = (width + kTileW - 1) / kTileW;
+    t->nty = (height + kTileH - 1) / kTileH;
     t->local_rows = height;
     std::memset(t->u, 0, sizeof t->u);
 
@@ -263,21 +248,24 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_tyj, n * sizeof(int32_t));
     A((void **)&t->d_height_own, sizeof(float));
     A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
+    A((void **)&t->d_ranges, t->nblocks * sizeof(TileRange));
+    A((void **)&t->d_row_ranges, t->nb * sizeof(TileRange));
     A((void **)&t->d_lut, sizeof lut);
-    A((void **)&t->d_slow, t->nprims * sizeof(uint32_t));
-    A((void **)&t->d_counters, 4 * sizeof(uint32_t));
+    A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
+    A((void **)&t->d_stats, 4 * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
-    if (err == hipSuccess) err = hipMemset(t->d_counters, 0, 4 * sizeof(uint32_t));
-    for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[k]);
+    if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
+    for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
+        for (int k = 0; k < 3 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
         return fail(err == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, m);
     }
+    t->d_rgba = t->d_rgba_own;
     t->d_height = t->d_height_own; t->tw = 1; t->th = 1;
-    int rc = alloc_targets(t);
-    if (rc == VF_OK) rc = refresh_tables(t, ctx->stream);
+    int rc = refresh_tables(t, ctx->stream);
     if (rc == VF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(VF_ERR_HIP, "table setup failed");
     if (rc != VF_OK) { std::string keep = g_err; vf_terrain_destroy(t); g_err = keep; return rc; }
     *out = t;
@@ -289,10 +277,10 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_lut,
-                     t->d_vis, t->d_rgba_own, t->d_slow, t->d_counters, t->d_scratch };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_ranges,
+                     t->d_row_ranges, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
 }
 
@@ -348,14 +336,12 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
-    if (!is_pow2(band_h)) return fail(VF_ERR_INVALID, "band_h must be a power of two");
+    if (!is_pow2(band_h) || band_h < (uint32_t)kTileH) return fail(VF_ERR_INVALID, "band_h must be a power of two >= 64 (the tile height)");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     t->rank = rank; t->nranks = nranks; t->band_h = band_h;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
-    // the row -> local row mapping changed: stale visibility words must not survive
-    VF_HIP_TRY(hipMemset(t->d_vis, 0, t->vis_capacity_px * sizeof(uint32_t)));
-    t->frame = 0;
+    t->rendered = false;
     return VF_OK;
 }
 
@@ -395,14 +381,47 @@ static void build_params(const vf_terrain *t, FrameParams &P)
         P.Lx = sx * inv; P.Ly = sy * inv; P.Lz = sz * inv;
     }
     P.hw = 0.5f * (float)t->W; P.hh = 0.5f * (float)t->H;
-    P.n = t->n; P.nm1 = t->n - 1;
-    P.W = t->W; P.H = t->H; P.tw = t->tw; P.th = t->th;
+    P.n = t->n; P.nm1 = t->n - 1; P.nb = t->nb;
+    P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
-    P.tag = 0;
     const SrgbTables &T = tables();
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
-    P.slow_cap = (uint32_t)(t->nprims > 0xFFFFFFFFull ? 0xFFFFFFFFull : t->nprims);
+}
+
+static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
+{
+    FrameParams P;
+    build_params(t, P);
+    AxisTables A = axis(t);
+    if (t->bounds_dirty) {
+        hipLaunchKernelGGL(k_block_bounds, dim3(t->nblocks), dim3(64), 0, s, t->n, t->nb, t->tw, A, t->d_height, t->d_bounds);
+        VF_HIP_TRY(hipGetLastError());
+        t->bounds_dirty = false;
+    }
+    const uint32_t local_tile_rows = (t->local_rows + kTileH - 1) / kTileH;
+    const uint32_t ntiles = t->ntx * local_tile_rows;
+    hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
+    if (t->timing) {
+        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, 4 * sizeof(uint32_t), s));
+        VF_HIP_TRY(hipEventRecord(ev[0], s));
+    }
+    hipLaunchKernelGGL(k_block_ranges, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges);
+    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
+    uint32_t *stats = t->timing ? t->d_stats : nullptr;
+    if (ntiles) {
+        if (write_vis)
+            hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_height, t->d_ranges, t->d_row_ranges,
+                               t->d_lut, t->ctx->d_thresh, t->d_rgba, t->d_vis, stats);
+        else
+            hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_height, t->d_ranges, t->d_row_ranges,
+                               t->d_lut, t->ctx->d_thresh, t->d_rgba, (uint32_t *)nullptr, stats);
+    }
+    if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[2], s)); t->timed_frames++; }
+    VF_HIP_TRY(hipGetLastError());
+    t->last_stream = s;
+    t->rendered = true;
+    return VF_OK;
 }
 
 int vf_terrain_render(vf_terrain *t, void *stream)
@@ -410,45 +429,7 @@ int vf_terrain_render(vf_terrain *t, void *stream)
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
-    FrameParams P;
-    build_params(t, P);
-    AxisTables A = axis(t);
-
-    if (t->bounds_dirty) {
-        hipLaunchKernelGGL(k_block_bounds, dim3(t->nblocks), dim3(256), 0, s, t->n, t->nbx, t->tw, A, t->d_height, t->d_bounds);
-        VF_HIP_TRY(hipGetLastError());
-        t->bounds_dirty = false;
-    }
-    const size_t npx = (size_t)t->local_rows * t->W;
-    if (t->use_tags) {
-        if (t->frame >= 127) {   // tag space exhausted: one real clear, then start over
-            VF_HIP_TRY(hipMemsetAsync(t->d_vis, 0, npx * sizeof(uint32_t), s));
-            t->frame = 0;
-        }
-        P.tag = (t->frame + 1u) << kTagShift;
-    } else {
-        VF_HIP_TRY(hipMemsetAsync(t->d_vis, 0, npx * sizeof(uint32_t), s));
-    }
-    t->frame++;
-
-    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[0], s));
-    hipLaunchKernelGGL(k_geometry, dim3(t->nblocks), dim3(kGeomThreads), 0, s, P, A, t->d_height, t->d_bounds, t->nbx,
-                       t->d_vis, t->d_slow, t->d_counters);
-    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[1], s));
-    hipLaunchKernelGGL(k_generic, dim3(1024), dim3(256), 0, s, P, A, t->d_height, t->d_vis, t->d_slow, t->d_counters);
-    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[2], s));
-    if (npx % 4 == 0 && t->W % 4 == 0)
-        hipLaunchKernelGGL(k_resolve<4>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, s, P, A, t->d_height, t->d_lut,
-                           t->ctx->d_thresh, t->d_vis, t->d_rgba, t->d_counters);
-    else
-        hipLaunchKernelGGL(k_resolve<1>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, P, A, t->d_height, t->d_lut,
-                           t->ctx->d_thresh, t->d_vis, t->d_rgba, t->d_counters);
-    if (t->timing) VF_HIP_TRY(hipEventRecord(t->ev[3], s));
-    VF_HIP_TRY(hipGetLastError());
-    t->last_stream = s;
-    t->rendered = true;
-    return VF_OK;
+    return render_impl(t, stream ? (hipStream_t)stream : t->ctx->stream, false);
 }
 
 int vf_terrain_sync(vf_terrain *t)
@@ -473,17 +454,17 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
 int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
 {
     if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
-    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    // the visibility tile normally lives and dies in LDS: re-render the current frame with the debug store enabled
+    const size_t npx = (size_t)t->W * t->H;
+    if (!t->d_vis) VF_HIP_TRY(hipMalloc(&t->d_vis, npx * sizeof(uint32_t)));
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    FrameParams P;
-    build_params(t, P);
-    P.tag = t->use_tags ? (t->frame << kTagShift) : 0u;   // tag of the frame just rendered
-    const size_t npx = (size_t)t->local_rows * t->W;
-    hipLaunchKernelGGL(k_decode_vis, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, t->ctx->stream, P, t->d_vis, t->d_scratch);
-    VF_HIP_TRY(hipGetLastError());
+    rc = render_impl(t, t->ctx->stream, true);
+    if (rc != VF_OK) return rc;
     VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
-    VF_HIP_TRY(hipMemcpy(dst, t->d_scratch, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    VF_HIP_TRY(hipMemcpy(dst, t->d_vis, (size_t)t->local_rows * t->W * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VF_OK;
 }
 
@@ -491,24 +472,33 @@ int vf_terrain_enable_timing(vf_terrain *t, int enable)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     t->timing = enable != 0;
+    t->timed_frames = 0;     // (re)start the averaging window
     return VF_OK;
 }
 
 int vf_terrain_timings(vf_terrain *t, vf_timings *out)
 {
     if (!t || !out) return fail(VF_ERR_INVALID, "NULL argument");
-    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    if (!t->timing || !t->rendered || t->timed_frames == 0) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    VF_HIP_TRY(hipEventSynchronize(t->ev[3]));
-    VF_HIP_TRY(hipEventElapsedTime(&out->geometry_ms, t->ev[0], t->ev[1]));
-    VF_HIP_TRY(hipEventElapsedTime(&out->generic_ms, t->ev[1], t->ev[2]));
-    VF_HIP_TRY(hipEventElapsedTime(&out->resolve_ms, t->ev[2], t->ev[3]));
-    VF_HIP_TRY(hipEventElapsedTime(&out->total_ms, t->ev[0], t->ev[3]));
+    // average over the frames recorded since vf_terrain_enable_timing (at most the last kTimingRing)
+    const uint32_t nf = t->timed_frames < (uint32_t)vf_terrain::kTimingRing ? t->timed_frames : (uint32_t)vf_terrain::kTimingRing;
+    double ranges = 0, tile = 0, total = 0;
+    for (uint32_t f = 0; f < nf; ++f) {
+        float a = 0, b = 0, c = 0;
+        VF_HIP_TRY(hipEventSynchronize(t->ev[f][2]));
+        VF_HIP_TRY(hipEventElapsedTime(&a, t->ev[f][0], t->ev[f][1]));
+        VF_HIP_TRY(hipEventElapsedTime(&b, t->ev[f][1], t->ev[f][2]));
+        VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][0], t->ev[f][2]));
+        ranges += a; tile += b; total += c;
+    }
+    out->ranges_ms = (float)(ranges / nf); out->tile_ms = (float)(tile / nf); out->total_ms = (float)(total / nf);
+    out->frames = nf;
     uint32_t c[4];
-    VF_HIP_TRY(hipMemcpy(c, t->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    out->generic_prims = c[2];
-    out->culled_blocks = c[3];
+    VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));
+    out->blocks_rasterised = c[0];
+    out->tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
     return VF_OK;
 }
 

@@ -1,17 +1,22 @@
 // vf_kernels.h -- the gfx950 kernels of the terrain raster path.
 //
 //   k_axis_tables     once per (grid, texture size): per-column / per-row vertex-shader terms
-//   k_block_bounds    once per height upload: min/max displaced height of every 32x32-cell block
-//   k_geometry        per frame: block cull -> 33x33 vertex tile in LDS -> triangle setup ->
-//                     small-triangle raster with atomicMax(primitive id) into the visibility buffer
-//   k_generic         per frame: clipped / large primitives, one workgroup slice per primitive
-//   k_resolve         per frame: fragment stage, visibility -> RGBA8 (sRGB)
-//   k_grid_generate   grid_generate (bit-exact make_grid)
+//   k_block_bounds    once per height upload: min/max displaced height of every 16x16-cell block
+//   k_block_ranges    per frame: conservative screen-tile rectangle of every block (+ per block row)
+//   k_tile            per frame: one workgroup per 64x64 screen tile.  Walks the block rows that can
+//                     touch the tile in DESCENDING primitive order, rebuilds each candidate block's
+//                     17x17 vertex tile in LDS, sets its 512 triangles up and rasterises them with
+//                     exact FP64 span solving into an LDS visibility tile (ds_max_u32), stops as soon
+//                     as every pixel of the tile is final, then runs the fragment stage on the LDS
+//                     tile and stores RGBA8 -- no framebuffer-sized intermediate ever touches HBM.
+//   k_grid_*          grid_generate (bit-exact make_grid)
 //   k_triangle        the triangle smoke path
 //   k_stitch_bands    multi-GPU de-interleave
 //
 // Painter's order: the reference pipeline has no depth buffer (src/terrain/pipeline.rs:133), so the
 // visible fragment is the LAST covering front-facing primitive in index order == max primitive id.
+// Primitive ids are cell-row major, so every primitive of block row r+1 beats every primitive of
+// block row r: after a block row has been rasterised, covered pixels are final.
 #pragma once
 #include "vf_device.h"
 
@@ -36,16 +41,15 @@ __global__ void k_axis_tables(uint32_t n, uint32_t tw, uint32_t th, float *xs, f
     tyj[i] = min(max(ty, 0), (int)th - 1);
 }
 
-// one workgroup per 32x32-cell block: exact min/max of h = h_tex + h_ana over its 33x33 vertices
-__global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t nbx, uint32_t tw, AxisTables A,
-                                                      const float *__restrict__ tex, float2 *__restrict__ bounds)
+// one workgroup per block: exact min/max of h = h_tex + h_ana over its 17x17 vertices
+__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, uint32_t tw, AxisTables A,
+                                                     const float *__restrict__ tex, float2 *__restrict__ bounds)
 {
-    __shared__ float smin[4], smax[4];
-    const uint32_t bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    const uint32_t bx = blockIdx.x % nb, by = blockIdx.x / nb;
     const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
     float lo = INFINITY, hi = -INFINITY;
     bool bad = false;
-    for (int v = threadIdx.x; v < kBlockVerts * kBlockVerts; v += 256) {
+    for (int v = threadIdx.x; v < kBlockVerts * kBlockVerts; v += 64) {
         uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
         uint32_t i = i0 + li, j = j0 + lj;
         if (i < n && j < n) {
@@ -59,171 +63,154 @@ __global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, uint32_t nbx, 
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    if (threadIdx.x == 0) bounds[blockIdx.x] = make_float2(lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per frame: which screen tiles can a block touch?  One workgroup per block row, one thread per block.
+// The block's vertices all lie in the box [x0,x1] x [hmin,hmax] x [z0,z1]; when its 8 corners are
+// regular (finite, w > 0, inside near/far) their screen bbox bounds every vertex of the block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
+                                                      TileRange *__restrict__ ranges, TileRange *__restrict__ row_ranges)
+{
+    __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
+    const uint32_t by = blockIdx.x;
+    if (threadIdx.x == 0) { s_rr[0] = 0xFFFF; s_rr[1] = 0xFFFF; s_rr[2] = -1; s_rr[3] = -1; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        lo = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        hi = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-        bounds[blockIdx.x] = make_float2(lo, hi);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// geometry + small-triangle raster
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void push_slow(uint32_t prim, uint32_t *slow_list, uint32_t *counters)
-{
-    uint32_t k = atomicAdd(&counters[0], 1u);
-    slow_list[k] = prim;   // capacity == total primitive count: cannot overflow
-}
-
-__device__ __forceinline__ void raster_small(const FrameParams &P, uint32_t prim, uint32_t fl0, uint32_t fl1, uint32_t fl2,
-                                             int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2,
-                                             uint32_t *__restrict__ vis, uint32_t *slow_list, uint32_t *counters)
-{
-    const uint32_t any = fl0 | fl1 | fl2, all = fl0 & fl1 & fl2;
-    if (any & F_BAD) return;                              // non-finite clip coordinate: primitive dropped
-    if (all & (F_NEAR | F_FAR)) return;                   // entirely outside the near or the far plane
-    if (any & (F_NEAR | F_FAR)) { push_slow(prim, slow_list, counters); return; }   // needs clipping
-    if (any & 8u) return;                                 // a vertex could not be projected (w <= 0)
-
-    const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
-    const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-    int32_t px0 = max((xmin + 127) >> 8, 0), px1 = min((xmax - 128) >> 8, (int32_t)P.W - 1);
-    int32_t py0 = max((ymin + 127) >> 8, 0), py1 = min((ymax - 128) >> 8, (int32_t)P.H - 1);
-    if (px0 > px1 || py0 > py1) return;                   // no pixel centre inside the bbox (the common case)
-    if ((uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kSmallExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kSmallExtent) {
-        push_slow(prim, slow_list, counters);
-        return;
-    }
-    // extents < 2^14: every product below fits in 32 bits
-    const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
-    if (area2 >= 0) return;                               // back-facing or degenerate
-    if ((px1 - px0 + 1) * (py1 - py0 + 1) > kSmallPixels) { push_slow(prim, slow_list, counters); return; }
-    const int32_t a0 = Y2 - Y1, b0 = -(X2 - X1);
-    const int32_t a1 = Y0 - Y2, b1 = -(X0 - X2);
-    const int32_t a2 = Y1 - Y0, b2 = -(X1 - X0);
-    // top-left rule as an integer bias: covered iff e + bias > 0  (bias 1 on top/left edges, else 0) -> e >= 0 / e > 0
-    const int32_t t0 = (a0 > 0 || (a0 == 0 && b0 > 0)) ? 1 : 0;
-    const int32_t t1 = (a1 > 0 || (a1 == 0 && b1 > 0)) ? 1 : 0;
-    const int32_t t2 = (a2 > 0 || (a2 == 0 && b2 > 0)) ? 1 : 0;
-    const uint32_t word = P.tag | (prim + 1u);
-    for (int32_t py = py0; py <= py1; ++py) {
-        if (!row_owned(P, (uint32_t)py)) continue;
-        const int32_t Py = py * 256 + 128;
-        uint32_t *row = vis + (size_t)local_row(P, (uint32_t)py) * P.W;
-        for (int32_t px = px0; px <= px1; ++px) {
-            const int32_t Px = px * 256 + 128;
-            // e_i = -E_jk(P), all differences < 2^15 in magnitude
-            const int32_t e0 = (Y2 - Y1) * (Px - X1) - (X2 - X1) * (Py - Y1);
-            const int32_t e1 = (Y0 - Y2) * (Px - X2) - (X0 - X2) * (Py - Y2);
-            const int32_t e2 = (Y1 - Y0) * (Px - X0) - (X1 - X0) * (Py - Y0);
-            if (e0 + t0 > 0 && e1 + t1 > 0 && e2 + t2 > 0) atomicMax(row + px, word);
-        }
-    }
-}
-
-__global__ __launch_bounds__(kGeomThreads) void k_geometry(FrameParams P, AxisTables A, const float *__restrict__ tex,
-                                                           const float2 *__restrict__ bounds, uint32_t nbx,
-                                                           uint32_t *__restrict__ vis, uint32_t *slow_list, uint32_t *counters)
-{
-    __shared__ int32_t sX[kBlockVerts * kBlockVerts];
-    __shared__ int32_t sY[kBlockVerts * kBlockVerts];
-    __shared__ uint8_t sF[kBlockVerts * kBlockVerts];
-    __shared__ int s_cull;
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
-    const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
-
-    // ---- block cull: project the 8 corners of the block's (x, h, z) bounding box ----------------
-    if (tid < 64) {
-        bool keep = true;       // conservative default
-        float xf = 0.f, yf = 0.f;
-        bool ok = false;
-        if (tid < 8) {
-            const float2 hb = bounds[blockIdx.x];
-            uint32_t i1 = min(i0 + kBlockCells, P.n - 1), j1 = min(j0 + kBlockCells, P.n - 1);
-            float x = A.xs[(tid & 1) ? i1 : i0], z = A.xs[(tid & 2) ? j1 : j0], h = (tid & 4) ? hb.y : hb.x;
+    for (uint32_t bx = threadIdx.x; bx < P.nb; bx += 256) {
+        const uint32_t b = by * P.nb + bx;
+        const float2 hb = bounds[b];
+        const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
+        const uint32_t i1 = min(i0 + kBlockCells, P.n - 1), j1 = min(j0 + kBlockCells, P.n - 1);
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        int regular = 0, out_near = 0, out_far = 0;
+        const bool hfinite = isfinite(hb.x) && isfinite(hb.y);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x = A.xs[(c & 1) ? i1 : i0], z = A.xs[(c & 2) ? j1 : j0], h = (c & 4) ? hb.y : hb.x;
             float vp[4], cp[4];
             mat_vec(P.view, x * P.spacing, h * P.exag, z * P.spacing, 1.0f, vp);
             mat_vec(P.proj, vp[0], vp[1], vp[2], vp[3], cp);
-            ok = finite4(cp[0], cp[1], cp[2], cp[3]) && cp[3] > 0.0f && cp[2] >= 0.0f && cp[2] <= cp[3];
-            if (ok) {
+            bool fin = finite4(cp[0], cp[1], cp[2], cp[3]);
+            // margins keep the whole-block rejection conservative against rounding at the clip planes
+            const float margin = 1e-3f * fmaxf(1.0f, fabsf(cp[3]));
+            out_near += fin && cp[2] < -margin;
+            out_far += fin && cp[2] - cp[3] > margin;
+            if (fin && cp[3] > 0.0f && cp[2] >= 0.0f && cp[2] <= cp[3]) {
                 float rw = 1.0f / cp[3];
-                xf = fmaf(cp[0] * rw, P.hw, P.hw);
-                yf = fmaf(-(cp[1] * rw), P.hh, P.hh);
-                ok = isfinite(xf) && isfinite(yf);
-            }
-        }
-        // all 8 corners must be regular for the bound to hold
-        unsigned long long okmask = __ballot(ok);
-        if ((okmask & 0xFFull) == 0xFFull) {
-            float xmin = tid < 8 ? xf : INFINITY, xmax = tid < 8 ? xf : -INFINITY;
-            float ymin = tid < 8 ? yf : INFINITY, ymax = tid < 8 ? yf : -INFINITY;
-            for (int o = 4; o > 0; o >>= 1) {
-                xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-                ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-            }
-            if (tid == 0) {
-                // one pixel of slack covers the rounding difference between corner and vertex arithmetic
-                if (xmax < -1.0f || ymax < -1.0f || xmin > (float)P.W + 1.0f || ymin > (float)P.H + 1.0f) keep = false;
-                else if (P.nranks > 1u) {
-                    int32_t ylo = (int32_t)fmaxf(floorf(ymin) - 1.0f, 0.0f);
-                    int32_t yhi = (int32_t)fminf(ceilf(ymax) + 1.0f, (float)P.H - 1.0f);
-                    uint32_t blo = (uint32_t)ylo >> P.band_shift, bhi = (uint32_t)yhi >> P.band_shift;
-                    if (bhi - blo + 1u < P.nranks) {
-                        keep = false;
-                        for (uint32_t b = blo; b <= bhi; ++b) keep |= (b % P.nranks) == P.rank;
-                    }
+                float xf = fmaf(cp[0] * rw, P.hw, P.hw), yf = fmaf(-(cp[1] * rw), P.hh, P.hh);
+                if (isfinite(xf) && isfinite(yf)) {
+                    ++regular;
+                    xmin = fminf(xmin, xf); xmax = fmaxf(xmax, xf);
+                    ymin = fminf(ymin, yf); ymax = fmaxf(ymax, yf);
                 }
             }
         }
-        if (tid == 0) {
-            s_cull = keep ? 0 : 1;
-            if (!keep) atomicAdd(&counters[1], 1u);
+        TileRange r;
+        if (hfinite && (out_near == 8 || out_far == 8)) {
+            r.x0 = 1; r.y0 = 1; r.x1 = 0; r.y1 = 0;            // clip z is affine in position: the whole block is clipped away
+        } else if (regular == 8) {
+            // one pixel of slack covers the rounding difference between corner and vertex arithmetic
+            if (xmax < -1.0f || ymax < -1.0f || xmin > (float)P.W + 1.0f || ymin > (float)P.H + 1.0f) {
+                r.x0 = 1; r.y0 = 1; r.x1 = 0; r.y1 = 0;
+            } else {
+                int px0 = (int)fmaxf(floorf(xmin) - 1.0f, 0.0f), px1 = (int)fminf(ceilf(xmax) + 1.0f, (float)P.W - 1.0f);
+                int py0 = (int)fmaxf(floorf(ymin) - 1.0f, 0.0f), py1 = (int)fminf(ceilf(ymax) + 1.0f, (float)P.H - 1.0f);
+                r.x0 = (uint16_t)(px0 / kTileW); r.x1 = (uint16_t)(px1 / kTileW);
+                r.y0 = (uint16_t)(py0 / kTileH); r.y1 = (uint16_t)(py1 / kTileH);
+            }
+        } else {
+            r.x0 = 0; r.y0 = 0; r.x1 = (uint16_t)(P.ntx - 1); r.y1 = (uint16_t)(P.nty - 1);   // no bound available: every tile
+        }
+        ranges[b] = r;
+        if (r.x0 <= r.x1) {
+            atomicMin(&s_rr[0], (int)r.x0); atomicMin(&s_rr[1], (int)r.y0);
+            atomicMax(&s_rr[2], (int)r.x1); atomicMax(&s_rr[3], (int)r.y1);
         }
     }
     __syncthreads();
-    if (s_cull) return;
-
-    // ---- vertex stage: 33 x 33 vertices -> snapped screen coordinates in LDS ---------------------
-    for (int v = tid; v < kBlockVerts * kBlockVerts; v += kGeomThreads) {
-        uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
-        uint32_t i = i0 + li, j = j0 + lj;
-        int32_t X = 0, Y = 0;
-        uint32_t fl = F_BAD;
-        if (i < P.n && j < P.n) {
-            float x, z;
-            ClipVert c = vertex_shader(P, A, tex, i, j, x, z);
-            fl = vertex_flags(c);
-            float rw;
-            if (!(fl & F_BAD) && !snap_vertex(c.x, c.y, c.w, P.hw, P.hh, X, Y, rw)) fl |= 8u;
-        }
-        sX[v] = X; sY[v] = Y; sF[v] = (uint8_t)fl;
-    }
-    __syncthreads();
-
-    // ---- primitive stage: 2 triangles per cell, 4 cells per thread -------------------------------
-#pragma unroll 1
-    for (int k = 0; k < (kBlockCells * kBlockCells) / kGeomThreads; ++k) {
-        const uint32_t c = tid + kGeomThreads * k;
-        const uint32_t lj = c >> 5, li = c & 31u;
-        const uint32_t i = i0 + li, j = j0 + lj;
-        if (i >= P.nm1 || j >= P.nm1) continue;
-        const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-        const int32_t Xa = sX[va], Ya = sY[va], Xb = sX[vb], Yb = sY[vb];
-        const int32_t Xc = sX[vc], Yc = sY[vc], Xd = sX[vd], Yd = sY[vd];
-        const uint32_t fa = sF[va], fb = sF[vb], fc = sF[vc], fd = sF[vd];
-        const uint32_t prim = 2u * (j * P.nm1 + i);
-        raster_small(P, prim, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb, vis, slow_list, counters);        // (a, c, b)
-        raster_small(P, prim + 1u, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd, vis, slow_list, counters);   // (b, c, d)
+    if (threadIdx.x == 0) {
+        TileRange rr;
+        if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
+        else { rr.x0 = (uint16_t)s_rr[0]; rr.y0 = (uint16_t)s_rr[1]; rr.x1 = (uint16_t)s_rr[2]; rr.y1 = (uint16_t)s_rr[3]; }
+        row_ranges[by] = rr;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// generic path: clipped or large primitives.  item = (list entry, row part)
+// tile kernel
 // ---------------------------------------------------------------------------------------------
+struct TileCtx {
+    uint32_t *vis;            // LDS, kTileW*kTileH words, skewed (see vis_index)
+    int32_t px_lo, px_hi;     // inclusive pixel rectangle of the tile, clipped to the target
+    int32_t py_lo, py_hi;
+};
+
+// LDS layout of the visibility tile: rotate each row by its row number so that a walk down a pixel
+// column visits all 32 banks (plain row-major would keep a column in one bank: 64-word row stride).
+__device__ __forceinline__ uint32_t vis_index(int32_t lx, int32_t ly) { return (uint32_t)ly * kTileW + (uint32_t)((lx + ly) & (kTileW - 1)); }
+
+__device__ __forceinline__ int32_t clamp_d2i(double v, int32_t lo, int32_t hi)
+{
+    v = fmax(v, (double)lo); v = fmin(v, (double)hi);
+    return (int32_t)v;
+}
+
+// Exact rasterisation of one unclipped front-facing-or-not triangle restricted to the tile.
+// Edge functions are evaluated in FP64: all operands are integers < 2^25 and every product/sum stays
+// below 2^53, so the arithmetic is exact; spans along the longer bbox axis are solved with one FP64
+// division per edge, exact for quotients below 2^20 (larger ones are clamped away) -- DESIGN.md.
+__device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
+                                            int32_t X2, int32_t Y2)
+{
+    const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+    const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+    const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
+    const int32_t py0 = max((ymin + 127) >> 8, T.py_lo), py1 = min((ymax - 128) >> 8, T.py_hi);
+    if (px0 > px1 || py0 > py1) return;
+    const double dX0 = X0, dY0 = Y0, dX1 = X1, dY1 = Y1, dX2 = X2, dY2 = Y2;
+    const double area2 = fma(dX1 - dX0, dY2 - dY0, -((dY1 - dY0) * (dX2 - dX0)));
+    if (area2 >= 0.0) return;                              // back-facing or degenerate
+    // inside-positive edge functions e_i(P) = A_i (Px - Xr_i) + B_i (Py - Yr_i); covered iff e_i + t_i > 0
+    const double A[3] = { dY2 - dY1, dY0 - dY2, dY1 - dY0 };
+    const double B[3] = { -(dX2 - dX1), -(dX0 - dX2), -(dX1 - dX0) };
+    const double XR[3] = { dX1, dX2, dX0 }, YR[3] = { dY1, dY2, dY0 };
+    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
+    const int32_t n_outer = cols ? px1 - px0 : py1 - py0, n_inner = cols ? py1 - py0 : px1 - px0;
+    // f_i(o, r) = base_i + SO_i*o + SI_i*r   with o/r = outer/inner pixel offsets from (px0, py0)
+    double base[3], SO[3], SI[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double tl = (A[i] > 0.0 || (A[i] == 0.0 && B[i] > 0.0)) ? 1.0 : 0.0;
+        base[i] = fma(A[i], (double)(px0 * 256 + 128) - XR[i], fma(B[i], (double)(py0 * 256 + 128) - YR[i], tl));
+        SO[i] = 256.0 * (cols ? A[i] : B[i]);
+        SI[i] = 256.0 * (cols ? B[i] : A[i]);
+    }
+    for (int32_t o = 0; o <= n_outer; ++o) {
+        int32_t lo = 0, hi = n_inner;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double alpha = fma(SO[i], (double)o, base[i]);   // f_i at inner offset 0
+            const double beta = SI[i];
+            if (beta > 0.0) {            // need r > -alpha/beta
+                if (alpha <= 0.0) lo = max(lo, clamp_d2i(floor(-alpha / beta) + 1.0, 0, n_inner + 1));
+            } else if (beta < 0.0) {     // need r < alpha/(-beta)  <=>  r <= floor((alpha-1)/(-beta))
+                if (alpha <= 0.0) hi = -1;
+                else hi = min(hi, clamp_d2i(floor((alpha - 1.0) / -beta), -1, n_inner));
+            } else if (alpha <= 0.0) hi = -1;
+        }
+        if (cols) {
+            const int32_t lx = px0 + o - T.px_lo;
+            for (int32_t r = lo; r <= hi; ++r) atomicMax(&T.vis[vis_index(lx, py0 + r - T.py_lo)], word);
+        } else {
+            const int32_t ly = py0 + o - T.py_lo;
+            for (int32_t r = lo; r <= hi; ++r) atomicMax(&T.vis[vis_index(px0 + r - T.px_lo, ly)], word);
+        }
+    }
+}
+
+// primitive -> clip-space vertices with varyings (used by the clipped path and the fragment stage)
 __device__ inline void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex, uint32_t prim, GVert v[3])
 {
     uint32_t vi[3], vj[3];
@@ -236,37 +223,43 @@ __device__ inline void load_prim(const FrameParams &P, const AxisTables &A, cons
     }
 }
 
-__global__ __launch_bounds__(256) void k_generic(FrameParams P, AxisTables A, const float *__restrict__ tex,
-                                                 uint32_t *__restrict__ vis, const uint32_t *slow_list, const uint32_t *counters)
+// clipped or oversized primitives: clip, fan, and scan each piece's bbox inside the tile with the
+// int64 coverage test.  Rare (primitives crossing the near plane, or > 65536 px across).
+__device__ __noinline__ void raster_generic(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex,
+                                            const TileCtx &T, uint32_t prim)
 {
-    const uint32_t count = min(counters[0], P.slow_cap);
-    const uint64_t items = (uint64_t)count * kGenericSplit;
-    for (uint64_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const uint32_t prim = slow_list[item / kGenericSplit];
-        const uint32_t part = (uint32_t)(item % kGenericSplit);
-        GVert v[3], poly[8];
-        load_prim(P, A, tex, prim, v);
-        const int np = clip_primitive(v, poly);
-        const uint32_t word = P.tag | (prim + 1u);
-        for (int f = 1; f + 1 < np; ++f) {
-            TriSetup T;
-            if (!setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, T)) continue;
-            const int32_t wpx = T.px1 - T.px0 + 1;
-            for (int32_t py = T.py0 + (int32_t)part; py <= T.py1; py += kGenericSplit) {
-                if (!row_owned(P, (uint32_t)py)) continue;
-                uint32_t *row = vis + (size_t)local_row(P, (uint32_t)py) * P.W;
-                for (int32_t dx = threadIdx.x; dx < wpx; dx += 256) {
-                    int64_t e[3];
-                    if (covers(T, T.px0 + dx, py, e)) atomicMax(row + T.px0 + dx, word);
-                }
+    GVert v[3], poly[8];
+    load_prim(P, A, tex, prim, v);
+    const int np = clip_primitive(v, poly);
+    for (int f = 1; f + 1 < np; ++f) {
+        TriSetup S;
+        if (!setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, S)) continue;
+        const int32_t px0 = max(S.px0, T.px_lo), px1 = min(S.px1, T.px_hi);
+        const int32_t py0 = max(S.py0, T.py_lo), py1 = min(S.py1, T.py_hi);
+        for (int32_t py = py0; py <= py1; ++py)
+            for (int32_t px = px0; px <= px1; ++px) {
+                int64_t e[3];
+                if (covers(S, px, py, e)) atomicMax(&T.vis[vis_index(px - T.px_lo, py - T.py_lo)], prim + 1u);
             }
-        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// fragment stage: visibility -> RGBA8
-// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void raster_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex, const TileCtx &T,
+                                            uint32_t prim, uint32_t fl0, uint32_t fl1, uint32_t fl2, int32_t X0, int32_t Y0,
+                                            int32_t X1, int32_t Y1, int32_t X2, int32_t Y2)
+{
+    const uint32_t any = fl0 | fl1 | fl2, all = fl0 & fl1 & fl2;
+    if (any & F_BAD) return;                              // non-finite clip coordinate: primitive dropped
+    if (all & (F_NEAR | F_FAR)) return;                   // entirely outside the near or the far plane
+    if (any & (F_NEAR | F_FAR)) { raster_generic(P, A, tex, T, prim); return; }   // needs clipping
+    if (any & F_NOSNAP) return;                           // a vertex could not be projected (w <= 0)
+    const uint32_t ex = (uint32_t)max(X0, max(X1, X2)) - (uint32_t)min(X0, min(X1, X2));
+    const uint32_t ey = (uint32_t)max(Y0, max(Y1, Y2)) - (uint32_t)min(Y0, min(Y1, Y2));
+    if (ex >= (uint32_t)kFastExtent || ey >= (uint32_t)kFastExtent) { raster_generic(P, A, tex, T, prim); return; }
+    raster_fast(T, prim + 1u, X0, Y0, X1, Y1, X2, Y2);
+}
+
+// ---- fragment stage ---------------------------------------------------------------------------
 struct ShadeTables { const float *lut; const float *thresh; };   // LDS: 256*3 linear LUT, 256 sRGB thresholds
 
 // fs_main (terrain.wgsl:69-91) + Rgba8UnormSrgb store
@@ -299,12 +292,26 @@ __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const 
     return out;
 }
 
+__device__ __noinline__ bool clipped_attributes(const FrameParams &P, const GVert v[3], int32_t px, int32_t py, float attr[3])
+{
+    GVert poly[8];
+    const int np = clip_primitive(v, poly);
+    bool hit = false;
+    for (int f = 1; f + 1 < np; ++f) {      // the last covering piece wins, as in the draw order
+        TriSetup T;
+        int64_t e[3];
+        if (setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
+    }
+    return hit;
+}
+
 __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex,
                                        const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
     GVert v[3];
     load_prim(P, A, tex, prim, v);
     bool plain = true;
+#pragma unroll
     for (int k = 0; k < 3; ++k) plain &= finite4(v[k].x, v[k].y, v[k].z, v[k].w) && !(v[k].z < 0.0f) && !(v[k].z > v[k].w);
     float attr[3] = { 0.f, 0.f, 0.f };
     bool hit = false;
@@ -313,62 +320,127 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A
         int64_t e[3];
         if (setup_triangle(v[0], v[1], v[2], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
     } else {
-        GVert poly[8];
-        const int np = clip_primitive(v, poly);
-        for (int f = 1; f + 1 < np; ++f) {      // the last covering piece wins, as in the draw order
-            TriSetup T;
-            int64_t e[3];
-            if (setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
-        }
+        hit = clipped_attributes(P, v, px, py, attr);
     }
-    if (!hit) return P.clear_rgba;   // unreachable when the visibility buffer is consistent
+    if (!hit) return P.clear_rgba;   // unreachable when the visibility tile is consistent
     return fragment_shader(P, S, attr);
 }
 
-template <int PPT>
-__global__ __launch_bounds__(256) void k_resolve(FrameParams P, AxisTables A, const float *__restrict__ tex,
-                                                 const float *__restrict__ lut_linear, const float *__restrict__ thresh,
-                                                 const uint32_t *__restrict__ vis, uint32_t *__restrict__ rgba, uint32_t *counters)
+__device__ __forceinline__ bool range_hits(const TileRange &r, uint32_t tx, uint32_t ty)
 {
-    __shared__ float s_lut[256 * 3];
-    __shared__ float s_thr[256];
-    for (int k = threadIdx.x; k < 768; k += 256) s_lut[k] = lut_linear[k];
-    s_thr[threadIdx.x] = thresh[threadIdx.x];
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {   // publish this frame's statistics, re-arm for the next frame
-        counters[2] = counters[0]; counters[3] = counters[1];
-        counters[0] = 0; counters[1] = 0;
-    }
-    ShadeTables S = { s_lut, s_thr };
-    const size_t npx = (size_t)P.local_rows * P.W;
-    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * PPT;
-    if (base >= npx) return;
-    uint32_t v[PPT], o[PPT];
-    if (PPT == 4) { uint4 q = *reinterpret_cast<const uint4 *>(vis + base); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-    else v[0] = vis[base];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        uint32_t word = v[k];
-        uint32_t id = word & kPrimMask;
-        bool live = P.tag ? ((word & ~kPrimMask) == P.tag && id != 0u) : (word != 0u);
-        if (!P.tag) id = word;
-        if (!live) { o[k] = P.clear_rgba; continue; }
-        size_t p = base + k;
-        uint32_t ly = (uint32_t)(p / P.W), px = (uint32_t)(p - (size_t)ly * P.W);
-        o[k] = shade_pixel(P, A, tex, S, id - 1u, (int32_t)px, (int32_t)global_row(P, ly));
-    }
-    if (PPT == 4) *reinterpret_cast<uint4 *>(rgba + base) = make_uint4(o[0], o[1], o[2], o[3]);
-    else rgba[base] = o[0];
+    return r.x0 <= r.x1 && tx >= r.x0 && tx <= r.x1 && ty >= r.y0 && ty <= r.y1;
 }
 
-// decode the tagged visibility words into prim+1 / 0 (debug + parity tests)
-__global__ void k_decode_vis(FrameParams P, const uint32_t *__restrict__ vis, uint32_t *__restrict__ out)
+template <bool WRITE_VIS>
+__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ tex,
+                                                       const TileRange *__restrict__ ranges, const TileRange *__restrict__ row_ranges,
+                                                       const float *__restrict__ lut_linear, const float *__restrict__ thresh,
+                                                       uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
 {
-    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (size_t)P.local_rows * P.W) return;
-    uint32_t word = vis[p];
-    if (P.tag) out[p] = ((word & ~kPrimMask) == P.tag) ? (word & kPrimMask) : 0u;
-    else out[p] = word;
+    __shared__ uint32_t s_vis[kTileW * kTileH];
+    __shared__ int32_t sX[kBlockVerts * kBlockVerts];
+    __shared__ int32_t sY[kBlockVerts * kBlockVerts];
+    __shared__ uint8_t sF[kBlockVerts * kBlockVerts];
+    __shared__ uint16_t s_cand[1024];
+    __shared__ uint32_t s_ncand;
+    __shared__ float s_lut[256 * 3];
+    __shared__ float s_thr[256];
+    __shared__ uint32_t s_part[8];   // per-wave covered-pixel counts, double-buffered by row parity
+
+    const uint32_t tid = threadIdx.x;
+    // tile coordinates: blockIdx -> (tile column, local tile row) -> global tile row of this shard
+    const uint32_t ttx = blockIdx.x % P.ntx, lty = blockIdx.x / P.ntx;
+    const uint32_t gy0 = global_row(P, lty * kTileH);              // band_h is a multiple of kTileH
+    const uint32_t tty = gy0 / kTileH;
+    TileCtx T;
+    T.vis = s_vis;
+    T.px_lo = (int32_t)(ttx * kTileW); T.px_hi = min(T.px_lo + kTileW, (int32_t)P.W) - 1;
+    T.py_lo = (int32_t)gy0;            T.py_hi = min(T.py_lo + kTileH, (int32_t)P.H) - 1;
+    const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
+
+    for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
+    for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
+    s_thr[tid] = thresh[tid];
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+
+    uint32_t blocks_done = 0;
+    uint32_t cand_total = 0;   // running value of the monotonic candidate counter (uniform)
+    for (int32_t by = (int32_t)P.nb - 1; by >= 0; --by) {
+        const TileRange rr = row_ranges[by];
+        if (!range_hits(rr, ttx, tty)) continue;                   // uniform
+        // ---- candidate blocks of this block row (order inside a row is irrelevant: atomicMax) ----
+        for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
+            const uint32_t bx = base + tid;
+            bool hit = false;
+            if (bx < P.nb) hit = range_hits(ranges[(uint32_t)by * P.nb + bx], ttx, tty);
+            const unsigned long long m = __ballot(hit);
+            uint32_t wbase = 0;
+            if ((tid & 63u) == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+            wbase = __shfl(wbase, 0);
+            if (hit) s_cand[(wbase + __popcll(m & ((1ull << (tid & 63u)) - 1ull))) & 1023u] = (uint16_t)bx;
+        }
+        __syncthreads();
+        const uint32_t cand_end = s_ncand;
+        const uint32_t nc = cand_end - cand_total;
+        for (uint32_t c = 0; c < nc; ++c) {
+            const uint32_t bx = s_cand[(cand_total + c) & 1023u];
+            const uint32_t i0 = bx * kBlockCells, j0 = (uint32_t)by * kBlockCells;
+            // ---- vertex stage: 17 x 17 vertices -> snapped screen coordinates in LDS ----
+            for (int v = tid; v < kBlockVerts * kBlockVerts; v += kTileThreads) {
+                const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
+                const uint32_t i = i0 + li, j = j0 + lj;
+                int32_t X = 0, Y = 0;
+                uint32_t fl = F_BAD;
+                if (i < P.n && j < P.n) {
+                    float x, z, rw;
+                    ClipVert cv = vertex_shader(P, A, tex, i, j, x, z);
+                    fl = vertex_flags(cv);
+                    if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
+                }
+                sX[v] = X; sY[v] = Y; sF[v] = (uint8_t)fl;
+            }
+            __syncthreads();
+            // ---- primitive stage: thread = cell, both triangles ----
+            {
+                const uint32_t lj = tid >> 4, li = tid & 15u;
+                const uint32_t i = i0 + li, j = j0 + lj;
+                if (i < P.nm1 && j < P.nm1) {
+                    const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+                    const int32_t Xa = sX[va], Ya = sY[va], Xb = sX[vb], Yb = sY[vb];
+                    const int32_t Xc = sX[vc], Yc = sY[vc], Xd = sX[vd], Yd = sY[vd];
+                    const uint32_t fa = sF[va], fb = sF[vb], fc = sF[vc], fd = sF[vd];
+                    const uint32_t prim = 2u * (j * P.nm1 + i);
+                    raster_prim(P, A, tex, T, prim, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
+                    raster_prim(P, A, tex, T, prim + 1u, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);     // (b, c, d)
+                }
+            }
+            __syncthreads();
+        }
+        blocks_done += nc;
+        cand_total = cand_end;
+        // ---- early out: pixels covered so far are final (lower block rows only hold smaller ids) ----
+        uint32_t covered = 0;
+        if (nc) for (int k = tid; k < kTileW * kTileH; k += kTileThreads) covered += s_vis[k] != 0u;
+        for (int o = 32; o > 0; o >>= 1) covered += __shfl_xor(covered, o);
+        if ((tid & 63u) == 0) s_part[(by & 1) * 4 + (tid >> 6)] = covered;
+        __syncthreads();   // also orders every thread's read of s_ncand before the next row's atomics
+        const uint32_t *part = s_part + (by & 1) * 4;
+        if (part[0] + part[1] + part[2] + part[3] >= tile_pixels) break;   // uniform
+    }
+    if (stats && tid == 0) atomicAdd(&stats[0], blocks_done);
+
+    // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
+    ShadeTables S = { s_lut, s_thr };
+    for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
+        const int32_t lx = k & (kTileW - 1), ly = k >> 6;
+        const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
+        if (px > T.px_hi || py > T.py_hi) continue;
+        const uint32_t id = s_vis[vis_index(lx, ly)];
+        const size_t o = (size_t)(lty * kTileH + (uint32_t)ly) * P.W + (uint32_t)px;
+        rgba[o] = id ? shade_pixel(P, A, tex, S, id - 1u, px, py) : P.clear_rgba;
+        if (WRITE_VIS) vis_out[o] = id;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -205,8 +205,8 @@ public:
         vf_timings tm;
         check(vf_terrain_timings(t, &tm));
         py::dict d;
-        d["geometry_ms"] = tm.geometry_ms; d["generic_ms"] = tm.generic_ms; d["resolve_ms"] = tm.resolve_ms;
-        d["total_ms"] = tm.total_ms; d["generic_prims"] = tm.generic_prims; d["culled_blocks"] = tm.culled_blocks;
+        d["ranges_ms"] = tm.ranges_ms; d["tile_ms"] = tm.tile_ms; d["total_ms"] = tm.total_ms;
+        d["blocks_rasterised"] = tm.blocks_rasterised; d["tiles"] = tm.tiles; d["frames"] = tm.frames;
         return d;
     }
     void enable_timing(bool on) { check(vf_terrain_enable_timing(t, on ? 1 : 0)); }
@@ -366,6 +366,14 @@ py::dict device_probe(py::object backend)
     return d;
 }
 
+// testing hook: the PNG encoder behind render_png / render_triangle_png, without touching the GPU
+py::bytes py_encode_png(py::array_t<uint8_t, py::array::c_style | py::array::forcecast> img)
+{
+    if (img.ndim() != 3 || img.shape(2) != 4) throw py::value_error("expected (H, W, 4) uint8");
+    std::vector<uint8_t> png = vfh::encode_png_rgba8(img.data(), (uint32_t)img.shape(1), (uint32_t)img.shape(0));
+    return py::bytes(reinterpret_cast<const char *>(png.data()), png.size());
+}
+
 template <class T>
 py::class_<T> bind_terrain(py::module_ &m, const char *name)
 {
@@ -401,6 +409,7 @@ PYBIND11_MODULE(_vulkan_forge, m)
     m.def("grid_generate", &grid_generate, py::arg("nx"), py::arg("nz"), py::arg("spacing") = std::make_tuple(1.0f, 1.0f),
           py::arg("origin") = "center");
     m.def("colormap_supported", &colormap_supported);
+    m.def("_encode_png_rgba8", &py_encode_png, py::arg("rgba"));
     m.def("camera_look_at", &camera_look_at, py::arg("eye"), py::arg("target"), py::arg("up"));
     m.def("camera_perspective", &camera_perspective, py::arg("fovy_deg"), py::arg("aspect"), py::arg("znear"), py::arg("zfar"),
           py::arg("clip_space") = "wgpu");
