@@ -225,35 +225,49 @@ def test_height_reupload_and_resize(cabi, oracle, luts):
         t.close()
 
 
-def test_stitch_kernel_and_device_buffers(cabi, oracle, luts):
-    import ctypes as C
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    W, H, G, nr, band = 256, 512, 64, 4, 64
-    u = oracle.default_uniforms(1, W, H)
-    h = heightmap(9, 64)
-    d_h = torch.from_numpy(h).cuda()
-    gathered = torch.zeros((nr, H // nr, W, 4), dtype=torch.uint8, device="cuda")
-    t = cabi.Terrain(W, H, G, luts["viridis"])
-    try:
-        t.set_uniforms(u)
-        t.set_height_device(d_h.data_ptr(), 64, 64)                 # borrowed texture already in HBM
-        stream = torch.cuda.current_stream().cuda_stream
-        for r in range(nr):
-            t.set_shard(r, nr, band)
-            t.set_output_device(gathered[r].data_ptr())             # render straight into the caller's buffer
-            t.render(stream)
-        t.sync()
-        image = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-        rc = t.lib.vf_stitch_bands_device(t.ctx, C.c_void_p(gathered.data_ptr()), C.c_void_p(image.data_ptr()), W, H, nr, band,
-                                          C.c_void_p(stream))
-        assert rc == 0
-        torch.cuda.synchronize()
-        ref_rgba, _ = oracle.render_terrain(u, W, H, G, h, luts["viridis"])
-        assert np.array_equal(image.cpu().numpy(), ref_rgba)
-    finally:
-        t.close()
+_TORCH_INTEROP = r"""
+import ctypes as C, os, sys
+import numpy as np
+import torch                      # first: the process then shares ONE HIP runtime (torch's) with libvf_hip.so
+sys.path.insert(0, os.environ["VF_ROOT"])
+import oracle
+from vulkan_forge_amd import cabi
+assert torch.cuda.is_available()
+W, H, G, nr, band = 256, 512, 64, 4, 64
+lut = np.load(os.path.join(os.environ["VF_ROOT"], "tests", "golden", "colormaps_rgba8.npz"))["viridis"]
+u = oracle.default_uniforms(1, W, H)
+h = np.random.default_rng(9).random((64, 64), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+d_h = torch.from_numpy(h).cuda()
+gathered = torch.zeros((nr, H // nr, W, 4), dtype=torch.uint8, device="cuda")
+t = cabi.Terrain(W, H, G, lut)
+t.set_uniforms(u)
+t.set_height_device(d_h.data_ptr(), 64, 64)                 # borrowed texture already in HBM
+stream = torch.cuda.current_stream().cuda_stream
+for r in range(nr):
+    t.set_shard(r, nr, band)
+    t.set_output_device(gathered[r].data_ptr())             # render straight into the caller's buffer
+    t.render(stream)
+t.sync()
+image = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+rc = t.lib.vf_stitch_bands_device(t.ctx, C.c_void_p(gathered.data_ptr()), C.c_void_p(image.data_ptr()), W, H, nr, band, C.c_void_p(stream))
+assert rc == 0
+torch.cuda.synchronize()
+ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
+assert np.array_equal(image.cpu().numpy(), ref)
+t.close()
+print("INTEROP_OK")
+"""
+
+
+def test_torch_device_buffers_streams_and_stitch_kernel():
+    """Caller-owned HBM buffers (torch tensors), the caller's stream, virtual ranks and the de-interleave kernel.
+    Runs in a child process that imports torch BEFORE the C-ABI library so both use one HIP runtime."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, VF_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", _TORCH_INTEROP], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "INTEROP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 # ---- grid_generate (bit-exact) and the triangle path --------------------------------------------------------
