@@ -125,6 +125,9 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
+/* diagnostics (timing enabled): per launched tile of the last frame, 3 words: candidate blocks processed,
+ * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock) */
+int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles);
 
 /* ---- grid_generate ----------------------------------------------------------------------- */
 /* make_grid (src/terrain/mesh.rs:35-90) computed on the GPU; outputs as the PyO3 wrapper returns

@@ -20,7 +20,7 @@ SYMBOLS = [
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
-    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
+    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_tile_stats", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device",
 ]
 
@@ -59,6 +59,7 @@ _PROTOS = {
     "vf_terrain_read_visibility": (_i, [_vp, _vp]),
     "vf_terrain_enable_timing": (_i, [_vp, _i]),
     "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "vf_terrain_debug_tile_stats": (_i, [_vp, _vp, _u32]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
     "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
@@ -151,6 +152,13 @@ class Terrain:
 
     def enable_timing(self, on=True):
         self._check(self.lib.vf_terrain_enable_timing(self.t, int(on)))
+
+    def tile_stats(self):
+        """(ntiles, 3) u32: candidate blocks, raster ticks, raster+fragment ticks (10 ns) per launched tile."""
+        n = ((self.W + 63) // 64) * ((self.local_rows() + 63) // 64)
+        out = np.zeros((n, 3), np.uint32)
+        self._check(self.lib.vf_terrain_debug_tile_stats(self.t, out.ctypes.data, n))
+        return out
 
     def timings(self):
         tm = Timings()

@@ -12,10 +12,13 @@
 namespace vf {
 
 // ---- constants shared by the kernels -------------------------------------------------------
-constexpr int kBlockCells = 16;                 // grid block = 16 x 16 cells (512 primitives)
-constexpr int kBlockVerts = kBlockCells + 1;    // 17 x 17 vertices incl. the shared edges
+constexpr int kBlockCells = 8;                  // grid block = 8 x 8 cells (128 primitives) = the work item of one wave
+constexpr int kBlockVerts = kBlockCells + 1;    // 9 x 9 vertices incl. the shared edges
 constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (64*64*4 B = 16 KiB)
-constexpr int kTileThreads = 256;
+#ifndef VF_TILE_THREADS
+#define VF_TILE_THREADS 1024
+#endif
+constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 
 constexpr uint32_t F_NEAR = 1u, F_FAR = 2u, F_BAD = 4u, F_NOSNAP = 8u;
@@ -37,8 +40,8 @@ struct FrameParams {
     uint32_t clear_rgba;            // packed sRGB8 clear colour
 };
 
-// inclusive tile rectangle a grid block (or a whole block row) may touch; x0 > x1 = empty
-struct TileRange { uint16_t x0, y0, x1, y1; };
+// inclusive pixel rectangle (clamped to the target) a grid block, or a whole block row, may touch; x0 > x1 = empty
+struct PixelBox { int16_t x0, y0, x1, y1; };
 
 // ---- deterministic sin / cos ---------------------------------------------------------------
 __device__ __forceinline__ float sin_poly(float r)

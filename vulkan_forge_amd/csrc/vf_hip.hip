@@ -88,8 +88,8 @@ struct vf_terrain {
     uint32_t tw = 1, th = 1;
     bool bounds_dirty = true;
     float2 *d_bounds = nullptr;          // per block: min/max displaced height
-    TileRange *d_ranges = nullptr;       // per block: tile rectangle (per frame)
-    TileRange *d_row_ranges = nullptr;   // per block row
+    PixelBox *d_ranges = nullptr;       // per block: tile rectangle (per frame)
+    PixelBox *d_row_ranges = nullptr;   // per block row
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint32_t *d_rgba = nullptr;
@@ -248,11 +248,11 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_tyj, n * sizeof(int32_t));
     A((void **)&t->d_height_own, sizeof(float));
     A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
-    A((void **)&t->d_ranges, t->nblocks * sizeof(TileRange));
-    A((void **)&t->d_row_ranges, t->nb * sizeof(TileRange));
+    A((void **)&t->d_ranges, t->nblocks * sizeof(PixelBox));
+    A((void **)&t->d_row_ranges, t->nb * sizeof(PixelBox));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
-    A((void **)&t->d_stats, 4 * sizeof(uint32_t));
+    A((void **)&t->d_stats, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
@@ -406,7 +406,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, 4 * sizeof(uint32_t), s));
         VF_HIP_TRY(hipEventRecord(ev[0], s));
     }
-    hipLaunchKernelGGL(k_block_ranges, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges);
+    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges);
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     if (ntiles) {
@@ -465,6 +465,18 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
     if (rc != VF_OK) return rc;
     VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     VF_HIP_TRY(hipMemcpy(dst, t->d_vis, (size_t)t->local_rows * t->W * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles)
+{
+    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    uint32_t n = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
+    if (n > max_tiles) n = max_tiles;
+    VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VF_OK;
 }
 

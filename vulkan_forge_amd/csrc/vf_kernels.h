@@ -1,14 +1,16 @@
 // vf_kernels.h -- the gfx950 kernels of the terrain raster path.
 //
 //   k_axis_tables     once per (grid, texture size): per-column / per-row vertex-shader terms
-//   k_block_bounds    once per height upload: min/max displaced height of every 16x16-cell block
-//   k_block_ranges    per frame: conservative screen-tile rectangle of every block (+ per block row)
+//   k_block_bounds    once per height upload: min/max displaced height of every 8x8-cell block
+//   k_block_boxes     per frame: conservative pixel rectangle of every block (+ per block row)
 //   k_tile            per frame: one workgroup per 64x64 screen tile.  Walks the block rows that can
-//                     touch the tile in DESCENDING primitive order, rebuilds each candidate block's
-//                     17x17 vertex tile in LDS, sets its 512 triangles up and rasterises them with
-//                     exact FP64 span solving into an LDS visibility tile (ds_max_u32), stops as soon
-//                     as every pixel of the tile is final, then runs the fragment stage on the LDS
-//                     tile and stores RGBA8 -- no framebuffer-sized intermediate ever touches HBM.
+//                     touch the tile in DESCENDING primitive order; each wave takes one candidate
+//                     block, rebuilds its 9x9 vertex tile in LDS, sets its 128 triangles up and
+//                     rasterises them with exact FP64 span solving into an LDS visibility tile
+//                     (ds_max_u32).  After every block row the covered pixels are final; final-pixel
+//                     masks cull occluded blocks, lines and pixels, and a fully final tile stops early.
+//                     The fragment stage then runs on the LDS tile and stores RGBA8 -- no
+//                     framebuffer-sized intermediate ever touches HBM.
 //   k_grid_*          grid_generate (bit-exact make_grid)
 //   k_triangle        the triangle smoke path
 //   k_stitch_bands    multi-GPU de-interleave
@@ -41,7 +43,7 @@ __global__ void k_axis_tables(uint32_t n, uint32_t tw, uint32_t th, float *xs, f
     tyj[i] = min(max(ty, 0), (int)th - 1);
 }
 
-// one workgroup per block: exact min/max of h = h_tex + h_ana over its 17x17 vertices
+// one wave per block: exact min/max of h = h_tex + h_ana over its 9x9 vertices
 __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, uint32_t tw, AxisTables A,
                                                      const float *__restrict__ tex, float2 *__restrict__ bounds)
 {
@@ -67,16 +69,16 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// per frame: which screen tiles can a block touch?  One workgroup per block row, one thread per block.
+// per frame: which pixels can a block touch?  One workgroup per block row, one thread per block.
 // The block's vertices all lie in the box [x0,x1] x [hmin,hmax] x [z0,z1]; when its 8 corners are
-// regular (finite, w > 0, inside near/far) their screen bbox bounds every vertex of the block.
+// regular (finite, w > 0, inside near/far with a margin) their screen bbox bounds every vertex.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
-                                                      TileRange *__restrict__ ranges, TileRange *__restrict__ row_ranges)
+__global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
+                                                     PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes)
 {
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
     const uint32_t by = blockIdx.x;
-    if (threadIdx.x == 0) { s_rr[0] = 0xFFFF; s_rr[1] = 0xFFFF; s_rr[2] = -1; s_rr[3] = -1; }
+    if (threadIdx.x == 0) { s_rr[0] = 0x7FFF; s_rr[1] = 0x7FFF; s_rr[2] = -1; s_rr[3] = -1; }
     __syncthreads();
     for (uint32_t bx = threadIdx.x; bx < P.nb; bx += 256) {
         const uint32_t b = by * P.nb + bx;
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables 
             mat_vec(P.view, x * P.spacing, h * P.exag, z * P.spacing, 1.0f, vp);
             mat_vec(P.proj, vp[0], vp[1], vp[2], vp[3], cp);
             bool fin = finite4(cp[0], cp[1], cp[2], cp[3]);
-            // margins keep the whole-block rejection conservative against rounding at the clip planes
+            // margins keep the classification conservative against rounding at the clip planes
             const float margin = 1e-3f * fmaxf(1.0f, fabsf(cp[3]));
             out_near += fin && cp[2] < -margin;
             out_far += fin && cp[2] - cp[3] > margin;
-            if (fin && cp[3] > 0.0f && cp[2] >= 0.0f && cp[2] <= cp[3]) {
+            if (fin && cp[3] > 0.0f && cp[2] >= margin && cp[3] - cp[2] >= margin) {
                 float rw = 1.0f / cp[3];
                 float xf = fmaf(cp[0] * rw, P.hw, P.hw), yf = fmaf(-(cp[1] * rw), P.hh, P.hh);
                 if (isfinite(xf) && isfinite(yf)) {
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables 
                 }
             }
         }
-        TileRange r;
+        PixelBox r;
+        const int16_t W1 = (int16_t)(P.W - 1), H1 = (int16_t)(P.H - 1);
         if (hfinite && (out_near == 8 || out_far == 8)) {
             r.x0 = 1; r.y0 = 1; r.x1 = 0; r.y1 = 0;            // clip z is affine in position: the whole block is clipped away
         } else if (regular == 8) {
@@ -115,15 +118,13 @@ __global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables 
             if (xmax < -1.0f || ymax < -1.0f || xmin > (float)P.W + 1.0f || ymin > (float)P.H + 1.0f) {
                 r.x0 = 1; r.y0 = 1; r.x1 = 0; r.y1 = 0;
             } else {
-                int px0 = (int)fmaxf(floorf(xmin) - 1.0f, 0.0f), px1 = (int)fminf(ceilf(xmax) + 1.0f, (float)P.W - 1.0f);
-                int py0 = (int)fmaxf(floorf(ymin) - 1.0f, 0.0f), py1 = (int)fminf(ceilf(ymax) + 1.0f, (float)P.H - 1.0f);
-                r.x0 = (uint16_t)(px0 / kTileW); r.x1 = (uint16_t)(px1 / kTileW);
-                r.y0 = (uint16_t)(py0 / kTileH); r.y1 = (uint16_t)(py1 / kTileH);
+                r.x0 = (int16_t)fmaxf(floorf(xmin) - 1.0f, 0.0f); r.x1 = (int16_t)fminf(ceilf(xmax) + 1.0f, (float)W1);
+                r.y0 = (int16_t)fmaxf(floorf(ymin) - 1.0f, 0.0f); r.y1 = (int16_t)fminf(ceilf(ymax) + 1.0f, (float)H1);
             }
         } else {
-            r.x0 = 0; r.y0 = 0; r.x1 = (uint16_t)(P.ntx - 1); r.y1 = (uint16_t)(P.nty - 1);   // no bound available: every tile
+            r.x0 = 0; r.y0 = 0; r.x1 = W1; r.y1 = H1;         // no bound available: the whole target
         }
-        ranges[b] = r;
+        boxes[b] = r;
         if (r.x0 <= r.x1) {
             atomicMin(&s_rr[0], (int)r.x0); atomicMin(&s_rr[1], (int)r.y0);
             atomicMax(&s_rr[2], (int)r.x1); atomicMax(&s_rr[3], (int)r.y1);
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        TileRange rr;
+        PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
-        else { rr.x0 = (uint16_t)s_rr[0]; rr.y0 = (uint16_t)s_rr[1]; rr.x1 = (uint16_t)s_rr[2]; rr.y1 = (uint16_t)s_rr[3]; }
-        row_ranges[by] = rr;
+        else { rr.x0 = (int16_t)s_rr[0]; rr.y0 = (int16_t)s_rr[1]; rr.x1 = (int16_t)s_rr[2]; rr.y1 = (int16_t)s_rr[3]; }
+        row_boxes[by] = rr;
     }
 }
 
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void k_block_ranges(FrameParams P, AxisTables 
 // ---------------------------------------------------------------------------------------------
 struct TileCtx {
     uint32_t *vis;            // LDS, kTileW*kTileH words, skewed (see vis_index)
+    const uint32_t *colfin;   // LDS, [64][2]: per tile column, bit r set = pixel (column, r) is final
+    const uint32_t *rowfin;   // LDS, [64][2]: per tile row, bit c set
     int32_t px_lo, px_hi;     // inclusive pixel rectangle of the tile, clipped to the target
     int32_t py_lo, py_hi;
 };
@@ -151,16 +154,20 @@ struct TileCtx {
 // column visits all 32 banks (plain row-major would keep a column in one bank: 64-word row stride).
 __device__ __forceinline__ uint32_t vis_index(int32_t lx, int32_t ly) { return (uint32_t)ly * kTileW + (uint32_t)((lx + ly) & (kTileW - 1)); }
 
-__device__ __forceinline__ int32_t clamp_d2i(double v, int32_t lo, int32_t hi)
+__device__ __forceinline__ uint64_t load_mask(const uint32_t *m, int32_t k) { return (uint64_t)m[2 * k] | ((uint64_t)m[2 * k + 1] << 32); }
+__device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits lo..hi inclusive, 0 <= lo <= hi <= 63
 {
-    v = fmax(v, (double)lo); v = fmin(v, (double)hi);
-    return (int32_t)v;
+    return (~0ull >> (63 - (hi - lo))) << lo;
 }
 
-// Exact rasterisation of one unclipped front-facing-or-not triangle restricted to the tile.
+// Exact rasterisation of one unclipped triangle restricted to the tile.
 // Edge functions are evaluated in FP64: all operands are integers < 2^25 and every product/sum stays
-// below 2^53, so the arithmetic is exact; spans along the longer bbox axis are solved with one FP64
-// division per edge, exact for quotients below 2^20 (larger ones are clamped away) -- DESIGN.md.
+// below 2^53, so the arithmetic is exact.  For each line of the shorter bbox axis the covered span
+// along the longer axis is bounded by the three half-planes alpha_i + beta_i * r > 0; the crossing is
+// estimated in FP32 (error < 1/4 for quotients < 2^20, larger ones are clamped away) and then fixed up
+// with the exact FP64 edge value, so the span is exactly the set of covered pixel centres.
+// Lines whose candidate pixels are all final (owned by a higher block row) are skipped unsolved, and
+// only non-final pixels are touched.
 __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
                                             int32_t X2, int32_t Y2)
 {
@@ -172,40 +179,68 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
     const double dX0 = X0, dY0 = Y0, dX1 = X1, dY1 = Y1, dX2 = X2, dY2 = Y2;
     const double area2 = fma(dX1 - dX0, dY2 - dY0, -((dY1 - dY0) * (dX2 - dX0)));
     if (area2 >= 0.0) return;                              // back-facing or degenerate
+    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
+    const int32_t n_outer = cols ? px1 - px0 : py1 - py0, n_inner = cols ? py1 - py0 : px1 - px0;
+    const int32_t o_base = cols ? px0 - T.px_lo : py0 - T.py_lo;     // tile-local index of outer line 0
+    const int32_t i_base = cols ? py0 - T.py_lo : px0 - T.px_lo;     // tile-local index of inner offset 0
+    const uint32_t *fin = cols ? T.colfin : T.rowfin;
+    const uint64_t seg = bit_range(i_base, i_base + n_inner);
     // inside-positive edge functions e_i(P) = A_i (Px - Xr_i) + B_i (Py - Yr_i); covered iff e_i + t_i > 0
     const double A[3] = { dY2 - dY1, dY0 - dY2, dY1 - dY0 };
     const double B[3] = { -(dX2 - dX1), -(dX0 - dX2), -(dX1 - dX0) };
     const double XR[3] = { dX1, dX2, dX0 }, YR[3] = { dY1, dY2, dY0 };
-    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
-    const int32_t n_outer = cols ? px1 - px0 : py1 - py0, n_inner = cols ? py1 - py0 : px1 - px0;
     // f_i(o, r) = base_i + SO_i*o + SI_i*r   with o/r = outer/inner pixel offsets from (px0, py0)
     double base[3], SO[3], SI[3];
+    float rSI[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double tl = (A[i] > 0.0 || (A[i] == 0.0 && B[i] > 0.0)) ? 1.0 : 0.0;
         base[i] = fma(A[i], (double)(px0 * 256 + 128) - XR[i], fma(B[i], (double)(py0 * 256 + 128) - YR[i], tl));
         SO[i] = 256.0 * (cols ? A[i] : B[i]);
         SI[i] = 256.0 * (cols ? B[i] : A[i]);
+        rSI[i] = SI[i] != 0.0 ? 1.0f / (float)SI[i] : 0.0f;
     }
+    const float q_lo = -4.0f, q_hi = (float)(n_inner + 4);
     for (int32_t o = 0; o <= n_outer; ++o) {
+        const uint64_t done = load_mask(fin, o_base + o);
+        const uint64_t open = ~done & seg;
+        if (open == 0ull) continue;
+        // ---- stage 1: conservative span from FP32 crossing estimates (exact alpha, relative error ~2^-22 => |error| < 1/4
+        //      inside the clamp range): true lo is one of k, k+1, k+2; true hi one of k+1, k, k-1, k-2 ----
+        double alpha[3];
+        int32_t kk[3];
+        int32_t lo_a = 0, hi_a = n_inner;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            alpha[i] = fma(SO[i], (double)o, base[i]);            // f_i at inner offset 0 (exact)
+            kk[i] = (int32_t)floorf(fminf(fmaxf(-(float)alpha[i] * rSI[i], q_lo), q_hi));
+            if (SI[i] > 0.0) lo_a = max(lo_a, kk[i]);
+            else if (SI[i] < 0.0) hi_a = min(hi_a, kk[i] + 1);
+            else if (alpha[i] <= 0.0) hi_a = -1;
+        }
+        if (lo_a > hi_a) continue;
+        if ((bit_range(i_base + lo_a, i_base + hi_a) & open) == 0ull) continue;   // nothing this line could still change
+        // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
         int32_t lo = 0, hi = n_inner;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double alpha = fma(SO[i], (double)o, base[i]);   // f_i at inner offset 0
             const double beta = SI[i];
-            if (beta > 0.0) {            // need r > -alpha/beta
-                if (alpha <= 0.0) lo = max(lo, clamp_d2i(floor(-alpha / beta) + 1.0, 0, n_inner + 1));
-            } else if (beta < 0.0) {     // need r < alpha/(-beta)  <=>  r <= floor((alpha-1)/(-beta))
-                if (alpha <= 0.0) hi = -1;
-                else hi = min(hi, clamp_d2i(floor((alpha - 1.0) / -beta), -1, n_inner));
-            } else if (alpha <= 0.0) hi = -1;
+            if (beta > 0.0) {            // smallest r with g(r) > 0
+                const double g0 = fma(beta, (double)kk[i], alpha[i]);
+                lo = max(lo, kk[i] + (g0 <= 0.0 ? ((g0 + beta) <= 0.0 ? 2 : 1) : 0));
+            } else if (beta < 0.0) {     // largest r with g(r) > 0
+                const double g1 = fma(beta, (double)(kk[i] + 1), alpha[i]);
+                const double g0 = g1 - beta, gm = g0 - beta;
+                hi = min(hi, g1 > 0.0 ? kk[i] + 1 : (g0 > 0.0 ? kk[i] : (gm > 0.0 ? kk[i] - 1 : kk[i] - 2)));
+            } else if (alpha[i] <= 0.0) hi = -1;
         }
-        if (cols) {
-            const int32_t lx = px0 + o - T.px_lo;
-            for (int32_t r = lo; r <= hi; ++r) atomicMax(&T.vis[vis_index(lx, py0 + r - T.py_lo)], word);
-        } else {
-            const int32_t ly = py0 + o - T.py_lo;
-            for (int32_t r = lo; r <= hi; ++r) atomicMax(&T.vis[vis_index(px0 + r - T.px_lo, ly)], word);
+        if (lo > hi) continue;
+        uint64_t bits = bit_range(i_base + lo, i_base + hi) & ~done;
+        const int32_t ol = o_base + o;
+        while (bits) {
+            const int32_t k = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            atomicMax(&T.vis[cols ? vis_index(ol, k) : vis_index(k, ol)], word);
         }
     }
 }
@@ -225,38 +260,50 @@ __device__ inline void load_prim(const FrameParams &P, const AxisTables &A, cons
 
 // clipped or oversized primitives: clip, fan, and scan each piece's bbox inside the tile with the
 // int64 coverage test.  Rare (primitives crossing the near plane, or > 65536 px across).
-__device__ __noinline__ void raster_generic(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex,
-                                            const TileCtx &T, uint32_t prim)
+__device__ __noinline__ void raster_generic(const GVert v[3], float hw, float hh, uint32_t W, uint32_t H, uint32_t *vis,
+                                            int32_t px_lo, int32_t px_hi, int32_t py_lo, int32_t py_hi, uint32_t word)
 {
-    GVert v[3], poly[8];
-    load_prim(P, A, tex, prim, v);
+    GVert poly[8];
     const int np = clip_primitive(v, poly);
     for (int f = 1; f + 1 < np; ++f) {
         TriSetup S;
-        if (!setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, S)) continue;
-        const int32_t px0 = max(S.px0, T.px_lo), px1 = min(S.px1, T.px_hi);
-        const int32_t py0 = max(S.py0, T.py_lo), py1 = min(S.py1, T.py_hi);
+        if (!setup_triangle(poly[0], poly[f], poly[f + 1], hw, hh, W, H, S)) continue;
+        const int32_t px0 = max(S.px0, px_lo), px1 = min(S.px1, px_hi);
+        const int32_t py0 = max(S.py0, py_lo), py1 = min(S.py1, py_hi);
         for (int32_t py = py0; py <= py1; ++py)
             for (int32_t px = px0; px <= px1; ++px) {
                 int64_t e[3];
-                if (covers(S, px, py, e)) atomicMax(&T.vis[vis_index(px - T.px_lo, py - T.py_lo)], prim + 1u);
+                if (covers(S, px, py, e)) atomicMax(&vis[vis_index(px - px_lo, py - py_lo)], word);
             }
     }
 }
 
-__device__ __forceinline__ void raster_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex, const TileCtx &T,
-                                            uint32_t prim, uint32_t fl0, uint32_t fl1, uint32_t fl2, int32_t X0, int32_t Y0,
-                                            int32_t X1, int32_t Y1, int32_t X2, int32_t Y2)
+// classification of one primitive against the tile: 0 = nothing to draw, 1 = fast path, 2 = generic path
+__device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uint32_t fl1, uint32_t fl2, int32_t X0, int32_t Y0,
+                                             int32_t X1, int32_t Y1, int32_t X2, int32_t Y2)
 {
     const uint32_t any = fl0 | fl1 | fl2, all = fl0 & fl1 & fl2;
-    if (any & F_BAD) return;                              // non-finite clip coordinate: primitive dropped
-    if (all & (F_NEAR | F_FAR)) return;                   // entirely outside the near or the far plane
-    if (any & (F_NEAR | F_FAR)) { raster_generic(P, A, tex, T, prim); return; }   // needs clipping
-    if (any & F_NOSNAP) return;                           // a vertex could not be projected (w <= 0)
-    const uint32_t ex = (uint32_t)max(X0, max(X1, X2)) - (uint32_t)min(X0, min(X1, X2));
-    const uint32_t ey = (uint32_t)max(Y0, max(Y1, Y2)) - (uint32_t)min(Y0, min(Y1, Y2));
-    if (ex >= (uint32_t)kFastExtent || ey >= (uint32_t)kFastExtent) { raster_generic(P, A, tex, T, prim); return; }
-    raster_fast(T, prim + 1u, X0, Y0, X1, Y1, X2, Y2);
+    if (any & F_BAD) return 0;                            // non-finite clip coordinate: primitive dropped
+    if (all & (F_NEAR | F_FAR)) return 0;                 // entirely outside the near or the far plane
+    if (any & (F_NEAR | F_FAR)) return 2;                 // needs clipping
+    if (any & F_NOSNAP) return 0;                         // a vertex could not be projected (w <= 0)
+    const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+    const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+    if ((uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kFastExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kFastExtent) return 2;
+    const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
+    const int32_t py0 = max((ymin + 127) >> 8, T.py_lo), py1 = min((ymax - 128) >> 8, T.py_hi);
+    if (px0 > px1 || py0 > py1) return 0;                 // no pixel centre of the tile inside the bbox
+    // facing: extents < 2^24, so the products fit comfortably in 64 bits
+    const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
+    if (area2 >= 0) return 0;                             // back-facing or degenerate
+    // occlusion: every candidate pixel already final
+    const bool cols = (px1 - px0) <= (py1 - py0);
+    const uint32_t *fin = cols ? T.colfin : T.rowfin;
+    const int32_t o0 = cols ? px0 - T.px_lo : py0 - T.py_lo, o1 = cols ? px1 - T.px_lo : py1 - T.py_lo;
+    const uint64_t seg = cols ? bit_range(py0 - T.py_lo, py1 - T.py_lo) : bit_range(px0 - T.px_lo, px1 - T.px_lo);
+    for (int32_t o = o0; o <= o1; ++o)
+        if (~load_mask(fin, o) & seg) return 1;
+    return 0;
 }
 
 // ---- fragment stage ---------------------------------------------------------------------------
@@ -292,7 +339,8 @@ __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const 
     return out;
 }
 
-__device__ __noinline__ bool clipped_attributes(const FrameParams &P, const GVert v[3], int32_t px, int32_t py, float attr[3])
+__device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, float hh, uint32_t W, uint32_t H, int32_t px, int32_t py,
+                                                float attr[3])
 {
     GVert poly[8];
     const int np = clip_primitive(v, poly);
@@ -300,7 +348,7 @@ __device__ __noinline__ bool clipped_attributes(const FrameParams &P, const GVer
     for (int f = 1; f + 1 < np; ++f) {      // the last covering piece wins, as in the draw order
         TriSetup T;
         int64_t e[3];
-        if (setup_triangle(poly[0], poly[f], poly[f + 1], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
+        if (setup_triangle(poly[0], poly[f], poly[f + 1], hw, hh, W, H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
     }
     return hit;
 }
@@ -320,74 +368,114 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A
         int64_t e[3];
         if (setup_triangle(v[0], v[1], v[2], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
     } else {
-        hit = clipped_attributes(P, v, px, py, attr);
+        hit = clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr);
     }
     if (!hit) return P.clear_rgba;   // unreachable when the visibility tile is consistent
     return fragment_shader(P, S, attr);
 }
 
-__device__ __forceinline__ bool range_hits(const TileRange &r, uint32_t tx, uint32_t ty)
+// does the block's pixel box touch the tile, and is any pixel of the overlap still open (not final)?
+__device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const TileCtx &T)
 {
-    return r.x0 <= r.x1 && tx >= r.x0 && tx <= r.x1 && ty >= r.y0 && ty <= r.y1;
+    if (b.x0 > b.x1) return false;
+    const int32_t x0 = max((int32_t)b.x0, T.px_lo), x1 = min((int32_t)b.x1, T.px_hi);
+    const int32_t y0 = max((int32_t)b.y0, T.py_lo), y1 = min((int32_t)b.y1, T.py_hi);
+    if (x0 > x1 || y0 > y1) return false;
+    if (x1 - x0 <= y1 - y0) {
+        const uint64_t seg = bit_range(y0 - T.py_lo, y1 - T.py_lo);
+        for (int32_t c = x0 - T.px_lo; c <= x1 - T.px_lo; ++c)
+            if (~load_mask(T.colfin, c) & seg) return true;
+    } else {
+        const uint64_t seg = bit_range(x0 - T.px_lo, x1 - T.px_lo);
+        for (int32_t r = y0 - T.py_lo; r <= y1 - T.py_lo; ++r)
+            if (~load_mask(T.rowfin, r) & seg) return true;
+    }
+    return false;
 }
 
 template <bool WRITE_VIS>
 __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ tex,
-                                                       const TileRange *__restrict__ ranges, const TileRange *__restrict__ row_ranges,
+                                                       const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
 {
+    constexpr int kWaves = kTileThreads / 64;
+    constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     __shared__ uint32_t s_vis[kTileW * kTileH];
-    __shared__ int32_t sX[kBlockVerts * kBlockVerts];
-    __shared__ int32_t sY[kBlockVerts * kBlockVerts];
-    __shared__ uint8_t sF[kBlockVerts * kBlockVerts];
-    __shared__ uint16_t s_cand[1024];
+    __shared__ int32_t sX[kWaves][kNV];
+    __shared__ int32_t sY[kWaves][kNV];
+    __shared__ uint8_t sF[kWaves][kNV + 3];
+    __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: surviving triangles of the current block
+    __shared__ uint16_t s_cand[2048];
     __shared__ uint32_t s_ncand;
+    __shared__ uint32_t s_colfin[kTileW * 2];
+    __shared__ uint32_t s_rowfin[kTileH * 2];
+    __shared__ uint32_t s_part[2 * kWaves];                // per-wave final-pixel counts, double-buffered by row parity
+    __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r can touch this tile (nb <= 1024)
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
-    __shared__ uint32_t s_part[8];   // per-wave covered-pixel counts, double-buffered by row parity
 
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t t_start = stats ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock, diagnostics only
     // tile coordinates: blockIdx -> (tile column, local tile row) -> global tile row of this shard
     const uint32_t ttx = blockIdx.x % P.ntx, lty = blockIdx.x / P.ntx;
     const uint32_t gy0 = global_row(P, lty * kTileH);              // band_h is a multiple of kTileH
-    const uint32_t tty = gy0 / kTileH;
     TileCtx T;
-    T.vis = s_vis;
+    T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
     T.px_lo = (int32_t)(ttx * kTileW); T.px_hi = min(T.px_lo + kTileW, (int32_t)P.W) - 1;
     T.py_lo = (int32_t)gy0;            T.py_hi = min(T.py_lo + kTileH, (int32_t)P.H) - 1;
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
-    s_thr[tid] = thresh[tid];
+    for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
+    for (int k = tid; k < kTileW * 2; k += kTileThreads) { s_colfin[k] = 0u; s_rowfin[k] = 0u; }
     if (tid == 0) s_ncand = 0;
+    __syncthreads();
+
+    // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
+    if (tid < 16) s_rows[tid] = 0ull;
+    __syncthreads();
+    for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
+        const uint32_t r = base + tid;
+        bool hit = false;
+        if (r < P.nb) {
+            const PixelBox rr = row_boxes[r];
+            hit = rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi && rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0 && m) s_rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
+    }
     __syncthreads();
 
     uint32_t blocks_done = 0;
     uint32_t cand_total = 0;   // running value of the monotonic candidate counter (uniform)
-    for (int32_t by = (int32_t)P.nb - 1; by >= 0; --by) {
-        const TileRange rr = row_ranges[by];
-        if (!range_hits(rr, ttx, tty)) continue;                   // uniform
-        // ---- candidate blocks of this block row (order inside a row is irrelevant: atomicMax) ----
+    bool tile_final = false;
+    for (int32_t w = (int32_t)((P.nb + 63u) / 64u) - 1; w >= 0 && !tile_final; --w) {
+      unsigned long long rows_left = s_rows[w];            // uniform
+      while (rows_left) {
+        const int32_t rb = 63 - __builtin_clzll(rows_left);
+        rows_left &= ~(1ull << rb);
+        const int32_t by = w * 64 + rb;                    // descending block rows
+        // ---- candidate blocks of this block row: box overlaps the tile AND still has an open pixel there ----
         for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
             const uint32_t bx = base + tid;
             bool hit = false;
-            if (bx < P.nb) hit = range_hits(ranges[(uint32_t)by * P.nb + bx], ttx, tty);
+            if (bx < P.nb) hit = block_is_candidate(boxes[(uint32_t)by * P.nb + bx], T);
             const unsigned long long m = __ballot(hit);
             uint32_t wbase = 0;
-            if ((tid & 63u) == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+            if (lane == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
             wbase = __shfl(wbase, 0);
-            if (hit) s_cand[(wbase + __popcll(m & ((1ull << (tid & 63u)) - 1ull))) & 1023u] = (uint16_t)bx;
+            if (hit) s_cand[(wbase + __popcll(m & ((1ull << lane) - 1ull))) & 2047u] = (uint16_t)bx;
         }
         __syncthreads();
         const uint32_t cand_end = s_ncand;
         const uint32_t nc = cand_end - cand_total;
-        for (uint32_t c = 0; c < nc; ++c) {
-            const uint32_t bx = s_cand[(cand_total + c) & 1023u];
+        // ---- one wave per candidate block: 9 x 9 vertices -> LDS, then lane = cell, both triangles ----
+        for (uint32_t c = wave; c < nc; c += kWaves) {
+            const uint32_t bx = s_cand[(cand_total + c) & 2047u];
             const uint32_t i0 = bx * kBlockCells, j0 = (uint32_t)by * kBlockCells;
-            // ---- vertex stage: 17 x 17 vertices -> snapped screen coordinates in LDS ----
-            for (int v = tid; v < kBlockVerts * kBlockVerts; v += kTileThreads) {
+            for (int v = lane; v < kNV; v += 64) {
                 const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
                 const uint32_t i = i0 + li, j = j0 + lj;
                 int32_t X = 0, Y = 0;
@@ -398,37 +486,87 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     fl = vertex_flags(cv);
                     if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
                 }
-                sX[v] = X; sY[v] = Y; sF[v] = (uint8_t)fl;
+                sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
             }
-            __syncthreads();
-            // ---- primitive stage: thread = cell, both triangles ----
+            __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler from reordering
+            // ---- pass A: lane = cell: classify both triangles, compact the survivors (ballot + prefix popcount) ----
+            uint32_t nsurv = 0;
             {
-                const uint32_t lj = tid >> 4, li = tid & 15u;
+                const uint32_t lj = lane >> 3, li = lane & 7u;
                 const uint32_t i = i0 + li, j = j0 + lj;
+                int k0 = 0, k1 = 0;
                 if (i < P.nm1 && j < P.nm1) {
                     const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-                    const int32_t Xa = sX[va], Ya = sY[va], Xb = sX[vb], Yb = sY[vb];
-                    const int32_t Xc = sX[vc], Yc = sY[vc], Xd = sX[vd], Yd = sY[vd];
-                    const uint32_t fa = sF[va], fb = sF[vb], fc = sF[vc], fd = sF[vd];
-                    const uint32_t prim = 2u * (j * P.nm1 + i);
-                    raster_prim(P, A, tex, T, prim, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
-                    raster_prim(P, A, tex, T, prim + 1u, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);     // (b, c, d)
+                    const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
+                    const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
+                    const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
+                    k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
+                    k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
+                    if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
+                        const uint32_t prim = 2u * (j * P.nm1 + i);
+                        GVert gv[3];
+                        if (k0 == 2) { load_prim(P, A, tex, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                        if (k1 == 2) { load_prim(P, A, tex, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                    }
                 }
+                const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t n0 = (uint32_t)__popcll(m0);
+                if (k0 == 1) sS[wave][__popcll(m0 & below)] = (uint8_t)(2u * lane);
+                if (k1 == 1) sS[wave][n0 + __popcll(m1 & below)] = (uint8_t)(2u * lane + 1u);
+                nsurv = n0 + (uint32_t)__popcll(m1);
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass B: dense lanes, one surviving triangle each ----
+            for (uint32_t sidx = lane; sidx < nsurv; sidx += 64) {
+                const uint32_t code = sS[wave][sidx];
+                const uint32_t cell = code >> 1, odd = code & 1u;
+                const uint32_t lj = cell >> 3, li = cell & 7u;
+                const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+                const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
+                const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
+                raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2]);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        __syncthreads();
         blocks_done += nc;
         cand_total = cand_end;
-        // ---- early out: pixels covered so far are final (lower block rows only hold smaller ids) ----
-        uint32_t covered = 0;
-        if (nc) for (int k = tid; k < kTileW * kTileH; k += kTileThreads) covered += s_vis[k] != 0u;
-        for (int o = 32; o > 0; o >>= 1) covered += __shfl_xor(covered, o);
-        if ((tid & 63u) == 0) s_part[(by & 1) * 4 + (tid >> 6)] = covered;
-        __syncthreads();   // also orders every thread's read of s_ncand before the next row's atomics
-        const uint32_t *part = s_part + (by & 1) * 4;
-        if (part[0] + part[1] + part[2] + part[3] >= tile_pixels) break;   // uniform
+        // ---- finality: pixels owned by this or a higher block row can never change again ----
+        // every wave scans kTileH / kWaves tile rows, lane = column: row masks by ballot, column masks by OR-accumulation
+        uint32_t nfinal = 0;
+        if (nc) {
+            constexpr int kRowsPerWave = kTileH / kWaves;
+            const uint32_t first_id = 2u * ((uint32_t)by * kBlockCells * P.nm1) + 1u;   // smallest (id + 1) of this block row
+            uint64_t colbits = 0;
+#pragma unroll 4
+            for (int k = 0; k < kRowsPerWave; ++k) {
+                const int32_t ly = (int32_t)wave * kRowsPerWave + k;
+                const bool fin = s_vis[vis_index((int32_t)lane, ly)] >= first_id;
+                const unsigned long long rm = __ballot(fin);
+                if (lane == 0) { s_rowfin[2 * ly] = (uint32_t)rm; s_rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
+                colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
+                nfinal += (uint32_t)__popcll(rm);
+            }
+            if ((uint32_t)colbits) atomicOr(&s_colfin[2 * lane], (uint32_t)colbits);
+            if ((uint32_t)(colbits >> 32)) atomicOr(&s_colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
+        }
+        if (lane == 0) s_part[(by & 1) * kWaves + wave] = nfinal;
+        __syncthreads();   // masks visible; also orders every thread's read of s_ncand before the next row's atomics
+        if (nc) {
+            const uint32_t *part = s_part + (by & 1) * kWaves;
+            uint32_t all = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) all += part[w];
+            if (all >= tile_pixels) { tile_final = true; break; }   // uniform: the whole tile is final
+        }
+      }
     }
-    if (stats && tid == 0) atomicAdd(&stats[0], blocks_done);
+    if (stats && tid == 0) {
+        atomicAdd(&stats[0], blocks_done);
+        stats[4 + 3 * blockIdx.x] = blocks_done;
+        stats[5 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // raster phase, 10 ns ticks
+    }
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
     ShadeTables S = { s_lut, s_thr };
@@ -441,6 +579,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         rgba[o] = id ? shade_pixel(P, A, tex, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
+    if (stats && tid == 0) stats[6 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // + fragment phase
 }
 
 // ---------------------------------------------------------------------------------------------
