@@ -18,6 +18,9 @@ constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (64*6
 #ifndef VF_TILE_THREADS
 #define VF_TILE_THREADS 1024
 #endif
+#ifndef VF_ROWS_PER_STEP
+#define VF_ROWS_PER_STEP 2
+#endif
 constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 
@@ -119,21 +122,35 @@ struct AxisTables {          // per-axis values of build_grid_xyuv + vs_main tha
     const int32_t *tyj;      // texel row for v_j
 };
 
+// Displaced-height cache, rebuilt by k_height_blocks after every height upload: for each 8x8-cell block
+// its 9x9 vertex heights h = h_tex + h_ana (terrain.wgsl:50-55) stored contiguously (81 floats = 324 B), so a
+// wave fetches a whole block with two coalesced loads and no dependent texel-index lookups.  Shared
+// edges are duplicated (1.27x the texture size).  kBlockStride floats per block.
+constexpr int kBlockStride = 81;
+__device__ __forceinline__ float cached_height(const float *__restrict__ hblk, uint32_t nb, uint32_t i, uint32_t j)
+{
+    const uint32_t bx = min(i >> 3, nb - 1u), by = min(j >> 3, nb - 1u);
+    return hblk[(size_t)(by * nb + bx) * kBlockStride + (j - 8u * by) * 9u + (i - 8u * bx)];
+}
+
 struct ClipVert { float x, y, z, w, h; };
 
-__device__ __forceinline__ ClipVert vertex_shader(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex,
-                                                  uint32_t i, uint32_t j, float &x_out, float &z_out)
+// h for grid vertex (i, j) exactly as vs_main forms it (terrain.wgsl:50-55)
+__device__ __forceinline__ float displaced_height(const AxisTables &A, const float *__restrict__ tex, uint32_t tw, uint32_t i, uint32_t j)
 {
-    float x = A.xs[i], z = A.xs[j];
-    float h_tex = tex[(size_t)A.tyj[j] * P.tw + A.txi[i]];
+    float h_tex = tex[(size_t)A.tyj[j] * tw + A.txi[i]];
     float h_ana = A.sinx[i] * 0.25f + A.cosz[j] * 0.25f;       // terrain.wgsl:39-41
-    float h = h_tex + h_ana;                                   // :55
+    return h_tex + h_ana;                                      // :55
+}
+
+// vs_main from the cached displaced height
+__device__ __forceinline__ ClipVert vertex_shader(const FrameParams &P, float x, float z, float h)
+{
     float vp[4], cp[4];
     mat_vec(P.view, x * P.spacing, h * P.exag, z * P.spacing, 1.0f, vp);
     mat_vec(P.proj, vp[0], vp[1], vp[2], vp[3], cp);
     ClipVert o;
     o.x = cp[0]; o.y = cp[1]; o.z = cp[2]; o.w = cp[3]; o.h = h;
-    x_out = x; z_out = z;
     return o;
 }
 

@@ -88,8 +88,11 @@ struct vf_terrain {
     uint32_t tw = 1, th = 1;
     bool bounds_dirty = true;
     float2 *d_bounds = nullptr;          // per block: min/max displaced height
+    float *d_hblk = nullptr;             // displaced-height cache: 81 floats per block
     PixelBox *d_ranges = nullptr;       // per block: tile rectangle (per frame)
     PixelBox *d_row_ranges = nullptr;   // per block row
+    float4 *d_cap_seg = nullptr;         // per block: capsule axis (screen space)
+    float *d_cap_rad = nullptr;          // per block: capsule radius
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint32_t *d_rgba = nullptr;
@@ -248,8 +251,11 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_tyj, n * sizeof(int32_t));
     A((void **)&t->d_height_own, sizeof(float));
     A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
+    A((void **)&t->d_hblk, (size_t)t->nblocks * kBlockStride * sizeof(float));
     A((void **)&t->d_ranges, t->nblocks * sizeof(PixelBox));
     A((void **)&t->d_row_ranges, t->nb * sizeof(PixelBox));
+    A((void **)&t->d_cap_seg, t->nblocks * sizeof(float4));
+    A((void **)&t->d_cap_rad, t->nblocks * sizeof(float));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
     A((void **)&t->d_stats, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t));
@@ -277,8 +283,8 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_ranges,
-                     t->d_row_ranges, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
+                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
@@ -395,7 +401,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     build_params(t, P);
     AxisTables A = axis(t);
     if (t->bounds_dirty) {
-        hipLaunchKernelGGL(k_block_bounds, dim3(t->nblocks), dim3(64), 0, s, t->n, t->nb, t->tw, A, t->d_height, t->d_bounds);
+        hipLaunchKernelGGL(k_height_blocks, dim3(t->nblocks), dim3(64), 0, s, t->n, t->nb, t->tw, A, t->d_height, t->d_hblk, t->d_bounds);
         VF_HIP_TRY(hipGetLastError());
         t->bounds_dirty = false;
     }
@@ -406,15 +412,15 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, 4 * sizeof(uint32_t), s));
         VF_HIP_TRY(hipEventRecord(ev[0], s));
     }
-    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges);
+    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad);
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     if (ntiles) {
         if (write_vis)
-            hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_height, t->d_ranges, t->d_row_ranges,
+            hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
                                t->d_lut, t->ctx->d_thresh, t->d_rgba, t->d_vis, stats);
         else
-            hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_height, t->d_ranges, t->d_row_ranges,
+            hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
                                t->d_lut, t->ctx->d_thresh, t->d_rgba, (uint32_t *)nullptr, stats);
     }
     if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[2], s)); t->timed_frames++; }

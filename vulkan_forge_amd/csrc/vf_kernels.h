@@ -1,7 +1,7 @@
 // vf_kernels.h -- the gfx950 kernels of the terrain raster path.
 //
 //   k_axis_tables     once per (grid, texture size): per-column / per-row vertex-shader terms
-//   k_block_bounds    once per height upload: min/max displaced height of every 8x8-cell block
+//   k_height_blocks   once per height upload: displaced-height cache (9x9 heights per 8x8-cell block) + block min/max
 //   k_block_boxes     per frame: conservative pixel rectangle of every block (+ per block row)
 //   k_tile            per frame: one workgroup per 64x64 screen tile.  Walks the block rows that can
 //                     touch the tile in DESCENDING primitive order; each wave takes one candidate
@@ -43,9 +43,10 @@ __global__ void k_axis_tables(uint32_t n, uint32_t tw, uint32_t th, float *xs, f
     tyj[i] = min(max(ty, 0), (int)th - 1);
 }
 
-// one wave per block: exact min/max of h = h_tex + h_ana over its 9x9 vertices
-__global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, uint32_t tw, AxisTables A,
-                                                     const float *__restrict__ tex, float2 *__restrict__ bounds)
+// one wave per block, once per height upload: the block's 9x9 displaced heights -> contiguous cache + exact min/max
+__global__ __launch_bounds__(64) void k_height_blocks(uint32_t n, uint32_t nb, uint32_t tw, AxisTables A,
+                                                      const float *__restrict__ tex, float *__restrict__ hblk,
+                                                      float2 *__restrict__ bounds)
 {
     const uint32_t bx = blockIdx.x % nb, by = blockIdx.x / nb;
     const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
@@ -54,17 +55,20 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, ui
     for (int v = threadIdx.x; v < kBlockVerts * kBlockVerts; v += 64) {
         uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
         uint32_t i = i0 + li, j = j0 + lj;
+        float h = 0.0f;
         if (i < n && j < n) {
-            float h = tex[(size_t)A.tyj[j] * tw + A.txi[i]] + (A.sinx[i] * 0.25f + A.cosz[j] * 0.25f);
+            h = displaced_height(A, tex, tw, i, j);
             bad |= !isfinite(h);
             lo = fminf(lo, h); hi = fmaxf(hi, h);
         }
+        hblk[(size_t)blockIdx.x * kBlockStride + v] = h;
     }
-    if (bad) { lo = -INFINITY; hi = INFINITY; }
+    bad = __any(bad);
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
+    if (bad) { lo = -INFINITY; hi = INFINITY; }
     if (threadIdx.x == 0) bounds[blockIdx.x] = make_float2(lo, hi);
 }
 
@@ -73,8 +77,15 @@ __global__ __launch_bounds__(64) void k_block_bounds(uint32_t n, uint32_t nb, ui
 // The block's vertices all lie in the box [x0,x1] x [hmin,hmax] x [z0,z1]; when its 8 corners are
 // regular (finite, w > 0, inside near/far with a margin) their screen bbox bounds every vertex.
 // ---------------------------------------------------------------------------------------------
+//
+// Besides the axis-aligned pixel box the kernel emits a capsule: every vertex (x, h, z) of the block projects onto
+// the screen segment between the projections of (x, hmin, z) and (x, hmax, z); those end points lie in the hulls of
+// the projected bottom / top faces, so the whole block lies within `rad` of the segment joining the two face centres
+// (rad = largest centre-to-corner distance + 1 px).  For oblique views the streak a block sweeps is long and thin
+// and the capsule rejects most of the tiles its bounding box crosses.
 __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
-                                                     PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes)
+                                                     PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes,
+                                                     float4 *__restrict__ cap_seg, float *__restrict__ cap_rad)
 {
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
     const uint32_t by = blockIdx.x;
@@ -86,10 +97,12 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
         const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
         const uint32_t i1 = min(i0 + kBlockCells, P.n - 1), j1 = min(j0 + kBlockCells, P.n - 1);
         float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        float cxs[8], cys[8];
         int regular = 0, out_near = 0, out_far = 0;
         const bool hfinite = isfinite(hb.x) && isfinite(hb.y);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+            cxs[c] = 0.0f; cys[c] = 0.0f;
             float x = A.xs[(c & 1) ? i1 : i0], z = A.xs[(c & 2) ? j1 : j0], h = (c & 4) ? hb.y : hb.x;
             float vp[4], cp[4];
             mat_vec(P.view, x * P.spacing, h * P.exag, z * P.spacing, 1.0f, vp);
@@ -104,6 +117,7 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
                 float xf = fmaf(cp[0] * rw, P.hw, P.hw), yf = fmaf(-(cp[1] * rw), P.hh, P.hh);
                 if (isfinite(xf) && isfinite(yf)) {
                     ++regular;
+                    cxs[c] = xf; cys[c] = yf;
                     xmin = fminf(xmin, xf); xmax = fmaxf(xmax, xf);
                     ymin = fminf(ymin, yf); ymax = fmaxf(ymax, yf);
                 }
@@ -125,6 +139,22 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
             r.x0 = 0; r.y0 = 0; r.x1 = W1; r.y1 = H1;         // no bound available: the whole target
         }
         boxes[b] = r;
+        float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
+        float rad = INFINITY;                                   // no capsule bound unless all 8 corners are regular
+        if (regular == 8) {
+            // corners 0..3 have h = hmin (bottom face), 4..7 h = hmax (top face)
+            const float ax = 0.25f * ((cxs[0] + cxs[1]) + (cxs[2] + cxs[3])), ay = 0.25f * ((cys[0] + cys[1]) + (cys[2] + cys[3]));
+            const float bx2 = 0.25f * ((cxs[4] + cxs[5]) + (cxs[6] + cxs[7])), by2 = 0.25f * ((cys[4] + cys[5]) + (cys[6] + cys[7]));
+            float r2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                r2 = fmaxf(r2, (cxs[c] - ax) * (cxs[c] - ax) + (cys[c] - ay) * (cys[c] - ay));
+                r2 = fmaxf(r2, (cxs[4 + c] - bx2) * (cxs[4 + c] - bx2) + (cys[4 + c] - by2) * (cys[4 + c] - by2));
+            }
+            seg = make_float4(ax, ay, bx2, by2);
+            rad = sqrtf(r2) * 1.0001f + 1.5f;                  // + rounding slack between corner and vertex arithmetic
+        }
+        cap_seg[b] = seg; cap_rad[b] = rad;
         if (r.x0 <= r.x1) {
             atomicMin(&s_rr[0], (int)r.x0); atomicMin(&s_rr[1], (int)r.y0);
             atomicMax(&s_rr[2], (int)r.x1); atomicMax(&s_rr[3], (int)r.y1);
@@ -246,13 +276,13 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
 }
 
 // primitive -> clip-space vertices with varyings (used by the clipped path and the fragment stage)
-__device__ inline void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex, uint32_t prim, GVert v[3])
+__device__ inline void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t prim, GVert v[3])
 {
     uint32_t vi[3], vj[3];
     prim_vertices(prim, P.nm1, vi, vj);
     for (int k = 0; k < 3; ++k) {
-        float x, z;
-        ClipVert c = vertex_shader(P, A, tex, vi[k], vj[k], x, z);
+        const float x = A.xs[vi[k]], z = A.xs[vj[k]];
+        ClipVert c = vertex_shader(P, x, z, cached_height(hblk, P.nb, vi[k], vj[k]));
         v[k].x = c.x; v[k].y = c.y; v[k].z = c.z; v[k].w = c.w;
         v[k].a[0] = c.h; v[k].a[1] = x; v[k].a[2] = z;     // varyings: height, xz (terrain.wgsl:63-64)
     }
@@ -353,11 +383,11 @@ __device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, floa
     return hit;
 }
 
-__device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ tex,
+__device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk,
                                        const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
     GVert v[3];
-    load_prim(P, A, tex, prim, v);
+    load_prim(P, A, hblk, prim, v);
     bool plain = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) plain &= finite4(v[k].x, v[k].y, v[k].z, v[k].w) && !(v[k].z < 0.0f) && !(v[k].z > v[k].w);
@@ -375,12 +405,29 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A
 }
 
 // does the block's pixel box touch the tile, and is any pixel of the overlap still open (not final)?
-__device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const TileCtx &T)
+// conservative: does the segment (a, b) come within `rad` of the tile rectangle?  (slab test on the tile grown by rad)
+__device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, const TileCtx &T)
+{
+    if (!(rad < 1e30f)) return true;
+    const float ex0 = (float)T.px_lo - rad, ex1 = (float)(T.px_hi + 1) + rad;
+    const float ey0 = (float)T.py_lo - rad, ey1 = (float)(T.py_hi + 1) + rad;
+    const float dx = seg.z - seg.x, dy = seg.w - seg.y;
+    float t0 = 0.0f, t1 = 1.0f;
+    if (fabsf(dx) < 1e-6f) { if (seg.x < ex0 || seg.x > ex1) return false; }
+    else { const float inv = 1.0f / dx; const float a = (ex0 - seg.x) * inv, b = (ex1 - seg.x) * inv; t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b)); }
+    if (fabsf(dy) < 1e-6f) { if (seg.y < ey0 || seg.y > ey1) return false; }
+    else { const float inv = 1.0f / dy; const float a = (ey0 - seg.y) * inv, b = (ey1 - seg.y) * inv; t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b)); }
+    return t0 <= t1 + 1e-4f;
+}
+
+__device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
+                                                   uint32_t idx, const TileCtx &T)
 {
     if (b.x0 > b.x1) return false;
     const int32_t x0 = max((int32_t)b.x0, T.px_lo), x1 = min((int32_t)b.x1, T.px_hi);
     const int32_t y0 = max((int32_t)b.y0, T.py_lo), y1 = min((int32_t)b.y1, T.py_hi);
     if (x0 > x1 || y0 > y1) return false;
+    if (!capsule_hits_tile(cap_seg[idx], cap_rad[idx], T)) return false;
     if (x1 - x0 <= y1 - y0) {
         const uint64_t seg = bit_range(y0 - T.py_lo, y1 - T.py_lo);
         for (int32_t c = x0 - T.px_lo; c <= x1 - T.px_lo; ++c)
@@ -394,19 +441,22 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const Tile
 }
 
 template <bool WRITE_VIS>
-__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ tex,
+__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ hblk,
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
+                                                       const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
 {
     constexpr int kWaves = kTileThreads / 64;
+    constexpr int kRowsPerStep = VF_ROWS_PER_STEP;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     __shared__ uint32_t s_vis[kTileW * kTileH];
     __shared__ int32_t sX[kWaves][kNV];
     __shared__ int32_t sY[kWaves][kNV];
     __shared__ uint8_t sF[kWaves][kNV + 3];
     __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: surviving triangles of the current block
-    __shared__ uint16_t s_cand[2048];
+    constexpr uint32_t kCandRing = 4096;                   // >= kRowsPerStep * max nb (1024)
+    __shared__ uint16_t s_cand[kCandRing];
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_colfin[kTileW * 2];
     __shared__ uint32_t s_rowfin[kTileH * 2];
@@ -450,39 +500,61 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
 
     uint32_t blocks_done = 0;
     uint32_t cand_total = 0;   // running value of the monotonic candidate counter (uniform)
-    bool tile_final = false;
-    for (int32_t w = (int32_t)((P.nb + 63u) / 64u) - 1; w >= 0 && !tile_final; --w) {
-      unsigned long long rows_left = s_rows[w];            // uniform
-      while (rows_left) {
-        const int32_t rb = 63 - __builtin_clzll(rows_left);
-        rows_left &= ~(1ull << rb);
-        const int32_t by = w * 64 + rb;                    // descending block rows
-        // ---- candidate blocks of this block row: box overlaps the tile AND still has an open pixel there ----
-        for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
-            const uint32_t bx = base + tid;
-            bool hit = false;
-            if (bx < P.nb) hit = block_is_candidate(boxes[(uint32_t)by * P.nb + bx], T);
-            const unsigned long long m = __ballot(hit);
-            uint32_t wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
-            wbase = __shfl(wbase, 0);
-            if (hit) s_cand[(wbase + __popcll(m & ((1ull << lane) - 1ull))) & 2047u] = (uint16_t)bx;
+    uint32_t step = 0;
+    // Block rows are visited in descending order, kRowsPerStep at a time: within a step the order of blocks is
+    // irrelevant (atomic max); after a step every pixel it covered is final.
+    int32_t wcur = (int32_t)((P.nb + 63u) / 64u) - 1;
+    unsigned long long rows_left = wcur >= 0 ? s_rows[wcur] : 0ull;      // uniform
+    for (;;) {
+        int32_t step_rows[kRowsPerStep];
+        int nrows = 0;
+        while (nrows < kRowsPerStep) {
+            while (!rows_left && wcur > 0) rows_left = s_rows[--wcur];
+            if (!rows_left) break;
+            const int32_t rb = 63 - __builtin_clzll(rows_left);
+            rows_left &= ~(1ull << rb);
+            step_rows[nrows++] = wcur * 64 + rb;
+        }
+        if (nrows == 0) break;
+        const int32_t by_low = step_rows[nrows - 1];           // lowest block row of the step
+        // ---- candidate blocks: box overlaps the tile AND still has an open pixel there ----
+#pragma unroll
+        for (int k = 0; k < kRowsPerStep; ++k) {
+            if (k >= nrows) break;
+            for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
+                const uint32_t bx = base + tid;
+                bool hit = false;
+                if (bx < P.nb) {
+                    const uint32_t bidx = (uint32_t)step_rows[k] * P.nb + bx;
+                    hit = block_is_candidate(boxes[bidx], cap_seg, cap_rad, bidx, T);
+                }
+                const unsigned long long m = __ballot(hit);
+                uint32_t wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (hit) s_cand[(wbase + __popcll(m & ((1ull << lane) - 1ull))) & (kCandRing - 1u)] = (uint16_t)(((uint32_t)k << 12) | bx);
+            }
         }
         __syncthreads();
         const uint32_t cand_end = s_ncand;
         const uint32_t nc = cand_end - cand_total;
         // ---- one wave per candidate block: 9 x 9 vertices -> LDS, then lane = cell, both triangles ----
         for (uint32_t c = wave; c < nc; c += kWaves) {
-            const uint32_t bx = s_cand[(cand_total + c) & 2047u];
+            const uint32_t code = s_cand[(cand_total + c) & (kCandRing - 1u)];
+            const uint32_t bx = code & 0xFFFu;
+            int32_t by = step_rows[0];
+#pragma unroll
+            for (int k = 1; k < kRowsPerStep; ++k) by = (code >> 12) == (uint32_t)k ? step_rows[k] : by;
             const uint32_t i0 = bx * kBlockCells, j0 = (uint32_t)by * kBlockCells;
+            const float *hb = hblk + (size_t)((uint32_t)by * P.nb + bx) * kBlockStride;
             for (int v = lane; v < kNV; v += 64) {
                 const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
                 const uint32_t i = i0 + li, j = j0 + lj;
                 int32_t X = 0, Y = 0;
                 uint32_t fl = F_BAD;
                 if (i < P.n && j < P.n) {
-                    float x, z, rw;
-                    ClipVert cv = vertex_shader(P, A, tex, i, j, x, z);
+                    float rw;
+                    ClipVert cv = vertex_shader(P, A.xs[i], A.xs[j], hb[v]);
                     fl = vertex_flags(cv);
                     if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
                 }
@@ -505,8 +577,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
                         const uint32_t prim = 2u * (j * P.nm1 + i);
                         GVert gv[3];
-                        if (k0 == 2) { load_prim(P, A, tex, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
-                        if (k1 == 2) { load_prim(P, A, tex, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                        if (k0 == 2) { load_prim(P, A, hblk, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                        if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
                     }
                 }
                 const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
@@ -537,7 +609,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         uint32_t nfinal = 0;
         if (nc) {
             constexpr int kRowsPerWave = kTileH / kWaves;
-            const uint32_t first_id = 2u * ((uint32_t)by * kBlockCells * P.nm1) + 1u;   // smallest (id + 1) of this block row
+            const uint32_t first_id = 2u * ((uint32_t)by_low * kBlockCells * P.nm1) + 1u;   // smallest (id + 1) of this step
             uint64_t colbits = 0;
 #pragma unroll 4
             for (int k = 0; k < kRowsPerWave; ++k) {
@@ -551,16 +623,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
             if ((uint32_t)colbits) atomicOr(&s_colfin[2 * lane], (uint32_t)colbits);
             if ((uint32_t)(colbits >> 32)) atomicOr(&s_colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
         }
-        if (lane == 0) s_part[(by & 1) * kWaves + wave] = nfinal;
+        if (lane == 0) s_part[(step & 1u) * kWaves + wave] = nfinal;
         __syncthreads();   // masks visible; also orders every thread's read of s_ncand before the next row's atomics
         if (nc) {
-            const uint32_t *part = s_part + (by & 1) * kWaves;
+            const uint32_t *part = s_part + (step & 1u) * kWaves;
             uint32_t all = 0;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) all += part[w];
-            if (all >= tile_pixels) { tile_final = true; break; }   // uniform: the whole tile is final
+            if (all >= tile_pixels) break;   // uniform: the whole tile is final
         }
-      }
+        ++step;
     }
     if (stats && tid == 0) {
         atomicAdd(&stats[0], blocks_done);
@@ -576,7 +648,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
         const size_t o = (size_t)(lty * kTileH + (uint32_t)ly) * P.W + (uint32_t)px;
-        rgba[o] = id ? shade_pixel(P, A, tex, S, id - 1u, px, py) : P.clear_rgba;
+        rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
     if (stats && tid == 0) stats[6 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // + fragment phase
