@@ -18,8 +18,8 @@ constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (64*6
 #ifndef VF_TILE_THREADS
 #define VF_TILE_THREADS 1024
 #endif
-#ifndef VF_ROWS_PER_STEP
-#define VF_ROWS_PER_STEP 2
+#ifndef VF_RESCAN_EVERY
+#define VF_RESCAN_EVERY 2
 #endif
 constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)

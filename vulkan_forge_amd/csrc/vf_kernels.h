@@ -440,6 +440,36 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const floa
     return false;
 }
 
+// One wave rescans the whole tile: which pixels are owned by a primitive with (id + 1) >= first_id?  Those can never
+// change again (only lower ids remain to be drawn).  Row masks by ballot, column masks by OR.  Returns the count.
+__device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin, uint32_t *rowfin, uint32_t lane, uint32_t first_id,
+                                                 int32_t row_begin, int32_t row_end)
+{
+    uint32_t nfinal = 0;
+    uint64_t colbits = 0;
+    for (int32_t ly = row_begin; ly < row_end; ++ly) {
+        const bool fin = vis[vis_index((int32_t)lane, ly)] >= first_id;
+        const unsigned long long rm = __ballot(fin);
+        if (lane == 0) { rowfin[2 * ly] = (uint32_t)rm; rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
+        colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
+        nfinal += (uint32_t)__popcll(rm);
+    }
+    if ((uint32_t)colbits) atomicOr(&colfin[2 * lane], (uint32_t)colbits);
+    if ((uint32_t)(colbits >> 32)) atomicOr(&colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
+    return nfinal;
+}
+
+// Tile kernel.  Structure per tile (one workgroup, kTileThreads / 64 waves):
+//   1. bitmask of the block rows whose pixel box touches the tile;
+//   2. chunks of up to kMaxSteps block rows in DESCENDING order: every wave tests the blocks of "its" rows against the
+//      tile (box, capsule, open pixels) and the hits form one work list (a row = one "step");
+//   3. waves pull blocks from the list with an LDS counter and rasterise them independently -- no barrier: painting is
+//      an atomic max, so the order inside the list does not matter for the result;
+//   4. a wave that finishes the last block of a step tries to advance the "final step" frontier: once every block of
+//      steps 0..s is done, pixels owned by ids >= first id of step s are final; the frontier owner rescans the tile and
+//      publishes the final-pixel masks that later blocks, lines and pixels are culled against (stale masks are merely
+//      conservative); a fully final tile stops early;
+//   5. fragment stage on the LDS tile.
 template <bool WRITE_VIS>
 __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ hblk,
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
@@ -448,20 +478,27 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
 {
     constexpr int kWaves = kTileThreads / 64;
-    constexpr int kRowsPerStep = VF_ROWS_PER_STEP;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
+    constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
+    constexpr int kMaxSteps = 128;                         // block rows per chunk
+    constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
+    constexpr int kRescanEvery = VF_RESCAN_EVERY;          // publish new masks when the frontier moved this many steps
     __shared__ uint32_t s_vis[kTileW * kTileH];
     __shared__ int32_t sX[kWaves][kNV];
     __shared__ int32_t sY[kWaves][kNV];
     __shared__ uint8_t sF[kWaves][kNV + 3];
     __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: surviving triangles of the current block
-    constexpr uint32_t kCandRing = 4096;                   // >= kRowsPerStep * max nb (1024)
-    __shared__ uint16_t s_cand[kCandRing];
-    __shared__ uint32_t s_ncand;
+    __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
+    __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
+    __shared__ uint32_t s_cnt[kMaxSteps + 1];              // candidates per step, then exclusive offsets
+    __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
+    __shared__ uint32_t s_firstid[kMaxSteps];
+    __shared__ uint16_t s_steprow[kMaxSteps];
     __shared__ uint32_t s_colfin[kTileW * 2];
     __shared__ uint32_t s_rowfin[kTileH * 2];
-    __shared__ uint32_t s_part[2 * kWaves];                // per-wave final-pixel counts, double-buffered by row parity
-    __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r can touch this tile (nb <= 1024)
+    __shared__ uint32_t s_part[kWaves];
+    __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
+    __shared__ uint32_t s_nrowsteps, s_nsteps, s_nlist, s_next, s_lock, s_done, s_frontier, s_published, s_blocks;
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
@@ -480,12 +517,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
     for (int k = tid; k < kTileW * 2; k += kTileThreads) { s_colfin[k] = 0u; s_rowfin[k] = 0u; }
-    if (tid == 0) s_ncand = 0;
-    __syncthreads();
-
-    // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
     if (tid < 16) s_rows[tid] = 0ull;
+    if (tid == 0) { s_done = 0; s_blocks = 0; }
     __syncthreads();
+    // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
     for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
         const uint32_t r = base + tid;
         bool hit = false;
@@ -498,145 +533,209 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     }
     __syncthreads();
 
-    uint32_t blocks_done = 0;
-    uint32_t cand_total = 0;   // running value of the monotonic candidate counter (uniform)
-    uint32_t step = 0;
-    // Block rows are visited in descending order, kRowsPerStep at a time: within a step the order of blocks is
-    // irrelevant (atomic max); after a step every pixel it covered is final.
-    int32_t wcur = (int32_t)((P.nb + 63u) / 64u) - 1;
-    unsigned long long rows_left = wcur >= 0 ? s_rows[wcur] : 0ull;      // uniform
+    const uint32_t hit_words = (P.nb + 63u) / 64u;
+    volatile uint32_t *v_pending = s_pending;
+    volatile uint32_t *v_done = &s_done, *v_frontier = &s_frontier, *v_published = &s_published;
+
     for (;;) {
-        int32_t step_rows[kRowsPerStep];
-        int nrows = 0;
-        while (nrows < kRowsPerStep) {
-            while (!rows_left && wcur > 0) rows_left = s_rows[--wcur];
-            if (!rows_left) break;
-            const int32_t rb = 63 - __builtin_clzll(rows_left);
-            rows_left &= ~(1ull << rb);
-            step_rows[nrows++] = wcur * 64 + rb;
+        // ---- chunk set-up 1: wave 0 lists the next (up to kMaxSteps) block rows in descending order ----
+        if (wave == 0) {
+            uint32_t n = 0;
+            for (int32_t w = 15; w >= 0 && n < (uint32_t)kMaxSteps; --w) {
+                unsigned long long m = s_rows[w];
+                while (m && n < (uint32_t)kMaxSteps) {
+                    const int32_t rb = 63 - __builtin_clzll(m);
+                    m &= ~(1ull << rb);
+                    if (lane == 0) s_steprow[n] = (uint16_t)(w * 64 + rb);
+                    ++n;
+                }
+            }
+            if (lane == 0) { s_nrowsteps = n; s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
         }
-        if (nrows == 0) break;
-        const int32_t by_low = step_rows[nrows - 1];           // lowest block row of the step
-        // ---- candidate blocks: box overlaps the tile AND still has an open pixel there ----
-#pragma unroll
-        for (int k = 0; k < kRowsPerStep; ++k) {
-            if (k >= nrows) break;
-            for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
-                const uint32_t bx = base + tid;
+        __syncthreads();
+        const uint32_t nrowsteps = s_nrowsteps;
+        if (nrowsteps == 0) break;                                  // uniform: nothing (left) to draw for this tile
+        // ---- chunk set-up 2: each wave tests the blocks of its rows against the tile; ballots are kept for the fill pass ----
+        for (uint32_t k = wave; k < nrowsteps; k += kWaves) {
+            const uint32_t by = s_steprow[k];
+            uint32_t cnt = 0;
+            for (uint32_t g = 0; g < hit_words; ++g) {
+                const uint32_t bx = g * 64u + lane;
                 bool hit = false;
                 if (bx < P.nb) {
-                    const uint32_t bidx = (uint32_t)step_rows[k] * P.nb + bx;
+                    const uint32_t bidx = by * P.nb + bx;
                     hit = block_is_candidate(boxes[bidx], cap_seg, cap_rad, bidx, T);
                 }
                 const unsigned long long m = __ballot(hit);
-                uint32_t wbase = 0;
-                if (lane == 0 && m) wbase = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
-                wbase = __shfl(wbase, 0);
-                if (hit) s_cand[(wbase + __popcll(m & ((1ull << lane) - 1ull))) & (kCandRing - 1u)] = (uint16_t)(((uint32_t)k << 12) | bx);
+                if (lane == 0) s_hit[k][g] = m;
+                cnt += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) { s_cnt[k] = cnt; s_firstid[k] = 2u * (by * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+        }
+        __syncthreads();
+        // ---- chunk set-up 3: exclusive offsets; rows that do not fit the list wait for the next chunk ----
+        if (wave == 0) {
+            uint32_t run = 0, nfit = 0;
+            for (uint32_t base = 0; base < nrowsteps; base += 64) {       // 64 rows at a time: wave-wide inclusive scan
+                const uint32_t k = base + lane;
+                const uint32_t c = k < nrowsteps ? s_cnt[k] : 0u;
+                uint32_t inc = c;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+                const uint32_t excl = run + inc - c;
+                const bool fits = k < nrowsteps && excl + c <= kChunk;
+                if (k < nrowsteps) s_cnt[k] = excl;
+                const unsigned long long fm = __ballot(fits);
+                // rows are admitted in order: stop at the first one that does not fit
+                const uint32_t lead = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
+                nfit += lead;
+                run += __shfl(inc, 63);
+                if (lead < 64u) break;
+            }
+            if (lane == 0) {
+                s_nsteps = nfit;
+                s_nlist = nfit ? 0u : 0u;
             }
         }
         __syncthreads();
-        const uint32_t cand_end = s_ncand;
-        const uint32_t nc = cand_end - cand_total;
-        // ---- one wave per candidate block: 9 x 9 vertices -> LDS, then lane = cell, both triangles ----
-        for (uint32_t c = wave; c < nc; c += kWaves) {
-            const uint32_t code = s_cand[(cand_total + c) & (kCandRing - 1u)];
-            const uint32_t bx = code & 0xFFFu;
-            int32_t by = step_rows[0];
-#pragma unroll
-            for (int k = 1; k < kRowsPerStep; ++k) by = (code >> 12) == (uint32_t)k ? step_rows[k] : by;
-            const uint32_t i0 = bx * kBlockCells, j0 = (uint32_t)by * kBlockCells;
-            const float *hb = hblk + (size_t)((uint32_t)by * P.nb + bx) * kBlockStride;
-            for (int v = lane; v < kNV; v += 64) {
-                const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
-                const uint32_t i = i0 + li, j = j0 + lj;
-                int32_t X = 0, Y = 0;
-                uint32_t fl = F_BAD;
-                if (i < P.n && j < P.n) {
-                    float rw;
-                    ClipVert cv = vertex_shader(P, A.xs[i], A.xs[j], hb[v]);
-                    fl = vertex_flags(cv);
-                    if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
-                }
-                sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
+        const uint32_t nsteps = s_nsteps;                            // >= 1: a single row always fits (nb <= 1024 < kChunk)
+        // ---- chunk set-up 4: fill the work list from the kept ballots; retire the rows from the to-do mask ----
+        for (uint32_t k = wave; k < nsteps; k += kWaves) {
+            const uint32_t by = s_steprow[k];
+            uint32_t pos = s_cnt[k], cnt = 0;
+            for (uint32_t g = 0; g < hit_words; ++g) {
+                const unsigned long long m = s_hit[k][g];
+                if ((m >> lane) & 1ull) s_list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
+                const uint32_t c = (uint32_t)__popcll(m);
+                pos += c; cnt += c;
             }
-            __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler from reordering
-            // ---- pass A: lane = cell: classify both triangles, compact the survivors (ballot + prefix popcount) ----
-            uint32_t nsurv = 0;
+            if (lane == 0) {
+                s_pending[k] = cnt;
+                atomicAnd(reinterpret_cast<unsigned long long *>(&s_rows[by >> 6]), ~(1ull << (by & 63u)));
+                if (k == nsteps - 1) s_nlist = pos;
+            }
+        }
+        __syncthreads();
+        const uint32_t nlist = s_nlist;
+
+        // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
+        uint32_t my_blocks = 0;
+        for (;;) {
+            if (*v_done) break;
+            uint32_t idx = 0;
+            if (lane == 0) idx = atomicAdd(&s_next, 1u);
+            idx = __shfl(idx, 0);
+            if (idx >= nlist) break;
+            const uint32_t entry = s_list[idx];
+            const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
+            // late culling against the masks published since the list was built (one column / row per lane)
+            bool live;
             {
-                const uint32_t lj = lane >> 3, li = lane & 7u;
-                const uint32_t i = i0 + li, j = j0 + lj;
-                int k0 = 0, k1 = 0;
-                if (i < P.nm1 && j < P.nm1) {
-                    const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-                    const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
-                    const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
-                    const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
-                    k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
-                    k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
-                    if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
-                        const uint32_t prim = 2u * (j * P.nm1 + i);
-                        GVert gv[3];
-                        if (k0 == 2) { load_prim(P, A, hblk, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
-                        if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                const PixelBox b = boxes[by * P.nb + bx];
+                const int32_t x0 = max((int32_t)b.x0, T.px_lo) - T.px_lo, x1 = min((int32_t)b.x1, T.px_hi) - T.px_lo;
+                const int32_t y0 = max((int32_t)b.y0, T.py_lo) - T.py_lo, y1 = min((int32_t)b.y1, T.py_hi) - T.py_lo;
+                const bool in = (int32_t)lane >= x0 && (int32_t)lane <= x1;
+                const uint64_t open = in ? (~load_mask(s_colfin, (int32_t)lane) & bit_range(y0, y1)) : 0ull;
+                live = __ballot(open != 0ull) != 0ull;
+            }
+            if (live) {
+                ++my_blocks;
+                const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
+                const float *hb = hblk + (size_t)(by * P.nb + bx) * kBlockStride;
+                // ---- vertex stage: 9 x 9 vertices -> snapped screen coordinates in this wave's LDS slot ----
+                for (int v = lane; v < kNV; v += 64) {
+                    const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
+                    const uint32_t i = i0 + li, j = j0 + lj;
+                    int32_t X = 0, Y = 0;
+                    uint32_t fl = F_BAD;
+                    if (i < P.n && j < P.n) {
+                        float rw;
+                        ClipVert cv = vertex_shader(P, A.xs[i], A.xs[j], hb[v]);
+                        fl = vertex_flags(cv);
+                        if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
                     }
+                    sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
                 }
-                const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const uint32_t n0 = (uint32_t)__popcll(m0);
-                if (k0 == 1) sS[wave][__popcll(m0 & below)] = (uint8_t)(2u * lane);
-                if (k1 == 1) sS[wave][n0 + __popcll(m1 & below)] = (uint8_t)(2u * lane + 1u);
-                nsurv = n0 + (uint32_t)__popcll(m1);
+                __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler from reordering
+                // ---- pass A: lane = cell: classify both triangles, compact the survivors (ballot + prefix popcount) ----
+                uint32_t nsurv = 0;
+                {
+                    const uint32_t lj = lane >> 3, li = lane & 7u;
+                    const uint32_t i = i0 + li, j = j0 + lj;
+                    int k0 = 0, k1 = 0;
+                    if (i < P.nm1 && j < P.nm1) {
+                        const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+                        const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
+                        const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
+                        const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
+                        k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
+                        k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
+                        if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
+                            const uint32_t prim = 2u * (j * P.nm1 + i);
+                            GVert gv[3];
+                            if (k0 == 2) { load_prim(P, A, hblk, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                            if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                        }
+                    }
+                    const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t n0 = (uint32_t)__popcll(m0);
+                    if (k0 == 1) sS[wave][__popcll(m0 & below)] = (uint8_t)(2u * lane);
+                    if (k1 == 1) sS[wave][n0 + __popcll(m1 & below)] = (uint8_t)(2u * lane + 1u);
+                    nsurv = n0 + (uint32_t)__popcll(m1);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- pass B: dense lanes, one surviving triangle each ----
+                for (uint32_t sidx = lane; sidx < nsurv; sidx += 64) {
+                    const uint32_t code = sS[wave][sidx];
+                    const uint32_t cell = code >> 1, odd = code & 1u;
+                    const uint32_t lj = cell >> 3, li = cell & 7u;
+                    const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+                    const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
+                    const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
+                    raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2]);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
-            // ---- pass B: dense lanes, one surviving triangle each ----
-            for (uint32_t sidx = lane; sidx < nsurv; sidx += 64) {
-                const uint32_t code = sS[wave][sidx];
-                const uint32_t cell = code >> 1, odd = code & 1u;
-                const uint32_t lj = cell >> 3, li = cell & 7u;
-                const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-                const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
-                const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2]);
+            // ---- completion: the DS queue of a wave is FIFO, so this decrement is ordered after the block's paints ----
+            uint32_t old = 0;
+            if (lane == 0) old = atomicSub(&s_pending[stepidx], 1u);
+            old = __shfl(old, 0);
+            if (old != 1u) continue;
+            // the step is complete: try to advance the frontier (first step that still has unfinished blocks)
+            uint32_t got = 0;
+            if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
+            got = __shfl(got, 0);
+            if (!got) continue;                                        // somebody else is publishing; masks may lag, never lie
+            uint32_t fr = *v_frontier;
+            while (fr < nsteps && v_pending[fr] == 0u) ++fr;
+            const uint32_t pub = *v_published;
+            if (fr > pub && (fr - pub >= (uint32_t)kRescanEvery || fr == nsteps)) {
+                // steps 0 .. fr-1 are complete: everything owned by ids >= first id of step fr-1 is final
+                const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], 0, kTileH);
+                if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) s_done = 1u; }
             }
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
+        }
+        if (lane == 0 && my_blocks) atomicAdd(&s_blocks, my_blocks);
+        __syncthreads();
+        if (s_done) break;                                             // uniform
+        // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
+        {
+            constexpr int kRowsPerWave = kTileH / kWaves;
+            const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane, s_firstid[nsteps - 1], (int32_t)wave * kRowsPerWave,
+                                                 (int32_t)(wave + 1) * kRowsPerWave);
+            if (lane == 0) s_part[wave] = nfinal;
         }
         __syncthreads();
-        blocks_done += nc;
-        cand_total = cand_end;
-        // ---- finality: pixels owned by this or a higher block row can never change again ----
-        // every wave scans kTileH / kWaves tile rows, lane = column: row masks by ballot, column masks by OR-accumulation
-        uint32_t nfinal = 0;
-        if (nc) {
-            constexpr int kRowsPerWave = kTileH / kWaves;
-            const uint32_t first_id = 2u * ((uint32_t)by_low * kBlockCells * P.nm1) + 1u;   // smallest (id + 1) of this step
-            uint64_t colbits = 0;
-#pragma unroll 4
-            for (int k = 0; k < kRowsPerWave; ++k) {
-                const int32_t ly = (int32_t)wave * kRowsPerWave + k;
-                const bool fin = s_vis[vis_index((int32_t)lane, ly)] >= first_id;
-                const unsigned long long rm = __ballot(fin);
-                if (lane == 0) { s_rowfin[2 * ly] = (uint32_t)rm; s_rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
-                colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
-                nfinal += (uint32_t)__popcll(rm);
-            }
-            if ((uint32_t)colbits) atomicOr(&s_colfin[2 * lane], (uint32_t)colbits);
-            if ((uint32_t)(colbits >> 32)) atomicOr(&s_colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
-        }
-        if (lane == 0) s_part[(step & 1u) * kWaves + wave] = nfinal;
-        __syncthreads();   // masks visible; also orders every thread's read of s_ncand before the next row's atomics
-        if (nc) {
-            const uint32_t *part = s_part + (step & 1u) * kWaves;
-            uint32_t all = 0;
+        uint32_t all = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) all += part[w];
-            if (all >= tile_pixels) break;   // uniform: the whole tile is final
-        }
-        ++step;
+        for (int w = 0; w < kWaves; ++w) all += s_part[w];
+        if (all >= tile_pixels) break;                                 // uniform: the whole tile is final
     }
+    __syncthreads();
     if (stats && tid == 0) {
-        atomicAdd(&stats[0], blocks_done);
-        stats[4 + 3 * blockIdx.x] = blocks_done;
+        atomicAdd(&stats[0], s_blocks);
+        stats[4 + 3 * blockIdx.x] = s_blocks;
         stats[5 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // raster phase, 10 ns ticks
     }
 
