@@ -155,7 +155,7 @@ class Terrain:
 
     def tile_stats(self):
         """(ntiles, 3) u32: candidate blocks, raster ticks, raster+fragment ticks (10 ns) per launched tile."""
-        n = ((self.W + 63) // 64) * ((self.local_rows() + 63) // 64)
+        n = self.timings()["tiles"]
         out = np.zeros((n, 3), np.uint32)
         self._check(self.lib.vf_terrain_debug_tile_stats(self.t, out.ctypes.data, n))
         return out

@@ -14,7 +14,10 @@ namespace vf {
 // ---- constants shared by the kernels -------------------------------------------------------
 constexpr int kBlockCells = 8;                  // grid block = 8 x 8 cells (128 primitives) = the work item of one wave
 constexpr int kBlockVerts = kBlockCells + 1;    // 9 x 9 vertices incl. the shared edges
-constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (64*64*4 B = 16 KiB)
+#ifndef VF_TILE_W
+#define VF_TILE_W 64
+#endif
+constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (power of two, <= 64 each: masks are 64-bit)
 #ifndef VF_TILE_THREADS
 #define VF_TILE_THREADS 1024
 #endif

@@ -198,8 +198,9 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // with the exact FP64 edge value, so the span is exactly the set of covered pixel centres.
 // Lines whose candidate pixels are all final (owned by a higher block row) are skipped unsolved, and
 // only non-final pixels are touched.
+// `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
 __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
-                                            int32_t X2, int32_t Y2)
+                                            int32_t X2, int32_t Y2, int32_t sub, int32_t nsub)
 {
     const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
     const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
@@ -228,10 +229,10 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         base[i] = fma(A[i], (double)(px0 * 256 + 128) - XR[i], fma(B[i], (double)(py0 * 256 + 128) - YR[i], tl));
         SO[i] = 256.0 * (cols ? A[i] : B[i]);
         SI[i] = 256.0 * (cols ? B[i] : A[i]);
-        rSI[i] = SI[i] != 0.0 ? 1.0f / (float)SI[i] : 0.0f;
+        rSI[i] = SI[i] != 0.0 ? __builtin_amdgcn_rcpf((float)SI[i]) : 0.0f;   // 1 ulp is plenty: only the estimate uses it
     }
     const float q_lo = -4.0f, q_hi = (float)(n_inner + 4);
-    for (int32_t o = 0; o <= n_outer; ++o) {
+    for (int32_t o = sub; o <= n_outer; o += nsub) {
         const uint64_t done = load_mask(fin, o_base + o);
         const uint64_t open = ~done & seg;
         if (open == 0ull) continue;
@@ -448,14 +449,16 @@ __device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin
     uint32_t nfinal = 0;
     uint64_t colbits = 0;
     for (int32_t ly = row_begin; ly < row_end; ++ly) {
-        const bool fin = vis[vis_index((int32_t)lane, ly)] >= first_id;
+        const bool fin = lane < (uint32_t)kTileW && vis[vis_index((int32_t)lane, ly)] >= first_id;
         const unsigned long long rm = __ballot(fin);
         if (lane == 0) { rowfin[2 * ly] = (uint32_t)rm; rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
         colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
         nfinal += (uint32_t)__popcll(rm);
     }
-    if ((uint32_t)colbits) atomicOr(&colfin[2 * lane], (uint32_t)colbits);
-    if ((uint32_t)(colbits >> 32)) atomicOr(&colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
+    if (lane < (uint32_t)kTileW) {
+        if ((uint32_t)colbits) atomicOr(&colfin[2 * lane], (uint32_t)colbits);
+        if ((uint32_t)(colbits >> 32)) atomicOr(&colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
+    }
     return nfinal;
 }
 
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
-    for (int k = tid; k < kTileW * 2; k += kTileThreads) { s_colfin[k] = 0u; s_rowfin[k] = 0u; }
+    for (int k = tid; k < kTileW * 2; k += kTileThreads) s_colfin[k] = 0u;
+    for (int k = tid; k < kTileH * 2; k += kTileThreads) s_rowfin[k] = 0u;
     if (tid < 16) s_rows[tid] = 0ull;
     if (tid == 0) { s_done = 0; s_blocks = 0; }
     __syncthreads();
@@ -684,15 +688,24 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     nsurv = n0 + (uint32_t)__popcll(m1);
                 }
                 __builtin_amdgcn_wave_barrier();
-                // ---- pass B: dense lanes, one surviving triangle each ----
-                for (uint32_t sidx = lane; sidx < nsurv; sidx += 64) {
-                    const uint32_t code = sS[wave][sidx];
-                    const uint32_t cell = code >> 1, odd = code & 1u;
-                    const uint32_t lj = cell >> 3, li = cell & 7u;
-                    const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-                    const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
-                    const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                    raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2]);
+                // ---- pass B: the survivors share the wave: with few of them, 2..64 lanes split the lines of one triangle ----
+                {
+                    uint32_t per = 1;                                   // lanes per survivor: largest power of two <= 64 / nsurv
+                    while (per < 64u && per * 2u * nsurv <= 64u) per *= 2u;
+                    const uint32_t shift = (uint32_t)__builtin_ctz(per);
+                    for (uint32_t sbase = 0; sbase < nsurv; sbase += 64u >> shift) {
+                        const uint32_t sidx = sbase + (lane >> shift);
+                        if (sidx < nsurv) {
+                            const uint32_t code = sS[wave][sidx];
+                            const uint32_t cell = code >> 1, odd = code & 1u;
+                            const uint32_t lj = cell >> 3, li = cell & 7u;
+                            const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+                            const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
+                            const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
+                            raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2],
+                                        (int32_t)(lane & (per - 1u)), (int32_t)per);
+                        }
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
     ShadeTables S = { s_lut, s_thr };
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
-        const int32_t lx = k & (kTileW - 1), ly = k >> 6;
+        const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
         const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
