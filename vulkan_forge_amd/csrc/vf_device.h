@@ -204,15 +204,6 @@ __device__ __forceinline__ uint32_t global_row(const FrameParams &P, uint32_t ly
     return (((lb * P.nranks) + P.rank) << P.band_shift) + (ly & (P.band_h - 1u));
 }
 
-// primitive id -> its three grid vertices in API order (indices [a,c,b, b,c,d], src/terrain/mod.rs:578-582)
-__device__ __forceinline__ void prim_vertices(uint32_t prim, uint32_t nm1, uint32_t vi[3], uint32_t vj[3])
-{
-    uint32_t cell = prim >> 1, odd = prim & 1u;
-    uint32_t j = cell / nm1, i = cell - j * nm1;
-    if (!odd) { vi[0] = i; vj[0] = j; vi[1] = i; vj[1] = j + 1; vi[2] = i + 1; vj[2] = j; }
-    else { vi[0] = i + 1; vj[0] = j; vi[1] = i; vj[1] = j + 1; vi[2] = i + 1; vj[2] = j + 1; }
-}
-
 // ---- generic (clipped / large) primitive handling --------------------------------------------
 struct GVert { float x, y, z, w; float a[3]; };
 struct SVert { int32_t X, Y; float rw; float a[3]; };
@@ -272,11 +263,12 @@ struct TriSetup {
 __device__ inline bool setup_triangle(const GVert &v0, const GVert &v1, const GVert &v2, float hw, float hh,
                                       uint32_t W, uint32_t H, TriSetup &T)
 {
-    const GVert *v[3] = { &v0, &v1, &v2 };
-    for (int k = 0; k < 3; ++k) {
-        if (!snap_vertex(v[k]->x, v[k]->y, v[k]->w, hw, hh, T.s[k].X, T.s[k].Y, T.s[k].rw)) return false;
-        for (int a = 0; a < 3; ++a) T.s[k].a[a] = v[k]->a[a];
-    }
+    // no pointer tables here: the vertices must stay in registers on the hot fragment path
+    if (!snap_vertex(v0.x, v0.y, v0.w, hw, hh, T.s[0].X, T.s[0].Y, T.s[0].rw)) return false;
+    if (!snap_vertex(v1.x, v1.y, v1.w, hw, hh, T.s[1].X, T.s[1].Y, T.s[1].rw)) return false;
+    if (!snap_vertex(v2.x, v2.y, v2.w, hw, hh, T.s[2].X, T.s[2].Y, T.s[2].rw)) return false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { T.s[0].a[a] = v0.a[a]; T.s[1].a[a] = v1.a[a]; T.s[2].a[a] = v2.a[a]; }
     const SVert *s = T.s;
     T.area2 = (int64_t)(s[1].X - s[0].X) * (s[2].Y - s[0].Y) - (int64_t)(s[1].Y - s[0].Y) * (s[2].X - s[0].X);
     if (T.area2 >= 0) return false;

@@ -93,6 +93,8 @@ struct vf_terrain {
     PixelBox *d_row_ranges = nullptr;   // per block row
     float4 *d_cap_seg = nullptr;         // per block: capsule axis (screen space)
     float *d_cap_rad = nullptr;          // per block: capsule radius
+    uint2 *d_work = nullptr;             // busy tiles of the frame: (tile, weight), heaviest first
+    uint32_t *d_work_count = nullptr;
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint32_t *d_rgba = nullptr;
@@ -256,6 +258,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_row_ranges, t->nb * sizeof(PixelBox));
     A((void **)&t->d_cap_seg, t->nblocks * sizeof(float4));
     A((void **)&t->d_cap_rad, t->nblocks * sizeof(float));
+    A((void **)&t->d_work, (size_t)t->ntx * t->nty * sizeof(uint2));
+    A((void **)&t->d_work_count, sizeof(uint32_t));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
     A((void **)&t->d_stats, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t));
@@ -284,7 +288,7 @@ void vf_terrain_destroy(vf_terrain *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
-                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
+                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_work, t->d_work_count, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
@@ -409,19 +413,23 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t ntiles = t->ntx * local_tile_rows;
     hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
     if (t->timing) {
-        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, 4 * sizeof(uint32_t), s));
+        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t), s));
         VF_HIP_TRY(hipEventRecord(ev[0], s));
     }
     hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad);
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     if (ntiles) {
+        uint32_t *vis = write_vis ? t->d_vis : nullptr;
+        VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count);
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count);
         if (write_vis)
             hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_rgba, t->d_vis, stats);
+                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, t->d_vis, stats);
         else
             hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_rgba, (uint32_t *)nullptr, stats);
+                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, (uint32_t *)nullptr, stats);
     }
     if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[2], s)); t->timed_frames++; }
     VF_HIP_TRY(hipGetLastError());

@@ -277,16 +277,24 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
 }
 
 // primitive -> clip-space vertices with varyings (used by the clipped path and the fragment stage)
-__device__ inline void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t prim, GVert v[3])
+__device__ __forceinline__ GVert load_vertex(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t i, uint32_t j)
 {
-    uint32_t vi[3], vj[3];
-    prim_vertices(prim, P.nm1, vi, vj);
-    for (int k = 0; k < 3; ++k) {
-        const float x = A.xs[vi[k]], z = A.xs[vj[k]];
-        ClipVert c = vertex_shader(P, x, z, cached_height(hblk, P.nb, vi[k], vj[k]));
-        v[k].x = c.x; v[k].y = c.y; v[k].z = c.z; v[k].w = c.w;
-        v[k].a[0] = c.h; v[k].a[1] = x; v[k].a[2] = z;     // varyings: height, xz (terrain.wgsl:63-64)
-    }
+    const float x = A.xs[i], z = A.xs[j];
+    const ClipVert c = vertex_shader(P, x, z, cached_height(hblk, P.nb, i, j));
+    GVert v;
+    v.x = c.x; v.y = c.y; v.z = c.z; v.w = c.w;
+    v.a[0] = c.h; v.a[1] = x; v.a[2] = z;                  // varyings: height, xz (terrain.wgsl:63-64)
+    return v;
+}
+__device__ __forceinline__ void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t prim,
+                                          GVert &v0, GVert &v1, GVert &v2)
+{
+    // indices [a,c,b, b,c,d] (src/terrain/mod.rs:578-582): even = (a, c, b), odd = (b, c, d)
+    const uint32_t cell = prim >> 1, odd = prim & 1u;
+    const uint32_t j = cell / P.nm1, i = cell - j * P.nm1;
+    v0 = load_vertex(P, A, hblk, odd ? i + 1 : i, j);
+    v1 = load_vertex(P, A, hblk, i, j + 1);
+    v2 = load_vertex(P, A, hblk, i + 1, odd ? j + 1 : j);
 }
 
 // clipped or oversized primitives: clip, fan, and scan each piece's bbox inside the tile with the
@@ -384,21 +392,21 @@ __device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, floa
     return hit;
 }
 
+__device__ __forceinline__ bool vertex_plain(const GVert &v) { return finite4(v.x, v.y, v.z, v.w) && !(v.z < 0.0f) && !(v.z > v.w); }
+
 __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk,
                                        const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
-    GVert v[3];
-    load_prim(P, A, hblk, prim, v);
-    bool plain = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) plain &= finite4(v[k].x, v[k].y, v[k].z, v[k].w) && !(v[k].z < 0.0f) && !(v[k].z > v[k].w);
+    GVert v0, v1, v2;
+    load_prim(P, A, hblk, prim, v0, v1, v2);
     float attr[3] = { 0.f, 0.f, 0.f };
     bool hit = false;
-    if (plain) {
+    if (vertex_plain(v0) && vertex_plain(v1) && vertex_plain(v2)) {
         TriSetup T;
         int64_t e[3];
-        if (setup_triangle(v[0], v[1], v[2], P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
+        if (setup_triangle(v0, v1, v2, P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
     } else {
+        const GVert v[3] = { v0, v1, v2 };                 // only the clipped path keeps the vertices in memory
         hit = clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr);
     }
     if (!hit) return P.clear_rgba;   // unreachable when the visibility tile is consistent
@@ -462,6 +470,79 @@ __device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin
     return nfinal;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame plan: one workgroup per owned tile decides whether any block row can touch it.  Background tiles (the
+// majority with the reference's default camera) are cleared right here with full-width stores; busy tiles are
+// appended to a work list with a weight (number of block rows in reach) and k_plan_sort orders the list
+// heaviest first, so the long-running tiles of the frame start first and the tail of the launch stays short.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_rect(const FrameParams &P, uint32_t tile, int32_t &px_lo, int32_t &px_hi, int32_t &py_lo, int32_t &py_hi,
+                                          uint32_t &lty)
+{
+    const uint32_t ttx = tile % P.ntx;
+    lty = tile / P.ntx;
+    px_lo = (int32_t)(ttx * kTileW); px_hi = min(px_lo + kTileW, (int32_t)P.W) - 1;
+    py_lo = (int32_t)global_row(P, lty * kTileH); py_hi = min(py_lo + kTileH, (int32_t)P.H) - 1;   // band_h is a multiple of kTileH
+}
+
+__global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ rgba,
+                                              uint32_t *__restrict__ vis_out, uint2 *__restrict__ work, uint32_t *__restrict__ work_count)
+{
+    __shared__ uint32_t s_hits;
+    int32_t px_lo, px_hi, py_lo, py_hi;
+    uint32_t lty;
+    tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi, lty);
+    if (threadIdx.x == 0) s_hits = 0;
+    __syncthreads();
+    uint32_t hits = 0;
+    for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
+        const PixelBox rr = row_boxes[r];
+        hits += (rr.x0 <= rr.x1 && rr.x1 >= px_lo && rr.x0 <= px_hi && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+    if ((threadIdx.x & 63u) == 0 && hits) atomicAdd(&s_hits, hits);
+    __syncthreads();
+    const uint32_t total = s_hits;
+    if (total) {
+        if (threadIdx.x == 0) work[atomicAdd(work_count, 1u)] = make_uint2(blockIdx.x, total);
+        return;
+    }
+    // background tile: clear colour (src/terrain/mod.rs:421), one row segment per wave-instruction
+    const int32_t w = px_hi - px_lo + 1, h = py_hi - py_lo + 1;
+    for (int32_t k = threadIdx.x; k < w * h; k += 256) {
+        const int32_t ly = k / w, lx = k - ly * w;
+        const size_t o = (size_t)(lty * kTileH + (uint32_t)ly) * P.W + (uint32_t)(px_lo + lx);
+        rgba[o] = P.clear_rgba;
+        if (vis_out) vis_out[o] = 0u;
+    }
+}
+
+// single workgroup: order the busy tiles by descending weight (bitonic sort in LDS, up to 65536 tiles in passes of 4096;
+// beyond one LDS load the order is only approximately global, which is all the scheduler needs)
+__global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count)
+{
+    __shared__ uint2 s[4096];
+    const uint32_t n = *work_count;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t m = min(4096u, n - base);
+        for (uint32_t k = threadIdx.x; k < 4096; k += 1024) s[k] = k < m ? work[base + k] : make_uint2(0xFFFFFFFFu, 0u);
+        __syncthreads();
+        for (uint32_t size = 2; size <= 4096; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t k = threadIdx.x; k < 2048; k += 1024) {
+                    const uint32_t lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
+                    const bool desc = (lo & size) == 0;              // descending blocks first
+                    const uint2 a = s[lo], b = s[hi];
+                    const bool swap = desc ? (a.y < b.y) : (a.y > b.y);
+                    if (swap) { s[lo] = b; s[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (uint32_t k = threadIdx.x; k < m; k += 1024) work[base + k] = s[k];
+        __syncthreads();
+    }
+}
+
 // Tile kernel.  Structure per tile (one workgroup, kTileThreads / 64 waves):
 //   1. bitmask of the block rows whose pixel box touches the tile;
 //   2. chunks of up to kMaxSteps block rows in DESCENDING order: every wave tests the blocks of "its" rows against the
@@ -478,8 +559,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
+                                                       const uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
 {
+    if (blockIdx.x >= *work_count) return;                 // the launch covers every owned tile; only the busy ones have work
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -507,13 +590,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t t_start = stats ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock, diagnostics only
-    // tile coordinates: blockIdx -> (tile column, local tile row) -> global tile row of this shard
-    const uint32_t ttx = blockIdx.x % P.ntx, lty = blockIdx.x / P.ntx;
-    const uint32_t gy0 = global_row(P, lty * kTileH);              // band_h is a multiple of kTileH
+    // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
+    const uint32_t tile = work[blockIdx.x].x;
+    uint32_t lty;
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
-    T.px_lo = (int32_t)(ttx * kTileW); T.px_hi = min(T.px_lo + kTileW, (int32_t)P.W) - 1;
-    T.py_lo = (int32_t)gy0;            T.py_hi = min(T.py_lo + kTileH, (int32_t)P.H) - 1;
+    tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi, lty);
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
@@ -675,9 +757,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                         k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
                         if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
                             const uint32_t prim = 2u * (j * P.nm1 + i);
-                            GVert gv[3];
-                            if (k0 == 2) { load_prim(P, A, hblk, prim, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
-                            if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                            GVert gv[3];                                               // in memory only on this rare path
+                            if (k0 == 2) { load_prim(P, A, hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                            if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
                         }
                     }
                     const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
@@ -748,8 +830,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     __syncthreads();
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
-        stats[4 + 3 * blockIdx.x] = s_blocks;
-        stats[5 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // raster phase, 10 ns ticks
+        stats[4 + 3 * tile] = s_blocks;
+        stats[5 + 3 * tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // raster phase, 10 ns ticks
     }
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
@@ -763,7 +845,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
-    if (stats && tid == 0) stats[6 + 3 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // + fragment phase
+    if (stats && tid == 0) stats[6 + 3 * tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // + fragment phase
 }
 
 // ---------------------------------------------------------------------------------------------
