@@ -4,7 +4,7 @@
   metric   Mpix/s terrain shade: W*H*frames / wall time, RGBA8 complete in HBM (rank 0 holds the gathered frame)
   workload C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
            (np.random.default_rng(20250816).random(float32)*0.5-0.25), default camera eye (3,2,3), viridis.
-           A "step" = one frame: k_block_ranges + k_tile (+ the band gather to rank 0 when N > 1).
+           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort + k_tile (+ the band gather to rank 0 when N > 1).
   N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): the frame is split into 64-row screen
            bands, band b belongs to rank b % N; every rank renders only its bands, then rank 0 receives each
            remote band directly into its place in the final image (point-to-point over xGMI).  Total work is
@@ -162,7 +162,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(4 * G * G + 4 * W * rows + 1024), "kernel_ms": tm["tile_ms"],
-                "ranges_kernel_ms": tm["ranges_ms"], "frames_averaged": tm["frames"], "rank_share_of_frame": share}
+                "other_kernels_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
 
     # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
     cpu = None

@@ -54,8 +54,9 @@ typedef struct vf_device_info {
 /* per-kernel device time (HIP events on the render stream), averaged over the frames rendered since
  * vf_terrain_enable_timing(t, 1) -- at most the last 64 */
 typedef struct vf_timings {
-    float ranges_ms;    /* k_block_ranges: per-block screen-tile rectangles */
-    float tile_ms;      /* k_tile: vertex + setup + LDS raster + fragment stage, one workgroup per screen tile */
+    float ranges_ms;    /* k_block_boxes: per-block pixel boxes and capsules */
+    float plan_ms;      /* k_plan + k_plan_sort: background clear, busy-tile list (heaviest first) */
+    float tile_ms;      /* k_tile: vertex + setup + LDS raster + fragment stage, one workgroup per busy screen tile */
     float total_ms;     /* first launch -> RGBA8 complete */
     uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out) */
     uint32_t tiles;             /* workgroups launched = owned screen tiles */

@@ -32,7 +32,7 @@ class DeviceInfo(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("ranges_ms", C.c_float), ("tile_ms", C.c_float), ("total_ms", C.c_float),
+    _fields_ = [("ranges_ms", C.c_float), ("plan_ms", C.c_float), ("tile_ms", C.c_float), ("total_ms", C.c_float),
                 ("blocks_rasterised", C.c_uint32), ("tiles", C.c_uint32), ("frames", C.c_uint32)]
 
 

@@ -100,10 +100,10 @@ struct vf_terrain {
     uint32_t *d_rgba = nullptr;
     uint32_t *d_vis = nullptr;           // only allocated for vf_terrain_read_visibility
     uint32_t *d_stats = nullptr;         // [0] (tile, block) pairs rasterised
-    // timing: a ring of (start, after ranges, after tile) event triplets, one per rendered frame
+    // timing: a ring of (start, after block boxes, after plan, after tile) events, one set per rendered frame
     static constexpr int kTimingRing = 64;
     bool timing = false;
-    hipEvent_t ev[kTimingRing][3] = {};
+    hipEvent_t ev[kTimingRing][4] = {};
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
     bool rendered = false;
@@ -267,7 +267,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
     for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
-        for (int k = 0; k < 3 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
+        for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -424,6 +424,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count);
+        if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], s));
         if (write_vis)
             hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
                                t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, t->d_vis, stats);
@@ -431,7 +432,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
             hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
                                t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, (uint32_t *)nullptr, stats);
     }
-    if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[2], s)); t->timed_frames++; }
+    if (t->timing) { if (!ntiles) VF_HIP_TRY(hipEventRecord(ev[2], s)); VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipGetLastError());
     t->last_stream = s;
     t->rendered = true;
@@ -510,16 +511,18 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
     if (rc != VF_OK) return rc;
     // average over the frames recorded since vf_terrain_enable_timing (at most the last kTimingRing)
     const uint32_t nf = t->timed_frames < (uint32_t)vf_terrain::kTimingRing ? t->timed_frames : (uint32_t)vf_terrain::kTimingRing;
-    double ranges = 0, tile = 0, total = 0;
+    double ranges = 0, plan = 0, tile = 0, total = 0;
     for (uint32_t f = 0; f < nf; ++f) {
-        float a = 0, b = 0, c = 0;
-        VF_HIP_TRY(hipEventSynchronize(t->ev[f][2]));
+        float a = 0, b = 0, c = 0, d = 0;
+        VF_HIP_TRY(hipEventSynchronize(t->ev[f][3]));
         VF_HIP_TRY(hipEventElapsedTime(&a, t->ev[f][0], t->ev[f][1]));
         VF_HIP_TRY(hipEventElapsedTime(&b, t->ev[f][1], t->ev[f][2]));
-        VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][0], t->ev[f][2]));
-        ranges += a; tile += b; total += c;
+        VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][2], t->ev[f][3]));
+        VF_HIP_TRY(hipEventElapsedTime(&d, t->ev[f][0], t->ev[f][3]));
+        ranges += a; plan += b; tile += c; total += d;
     }
-    out->ranges_ms = (float)(ranges / nf); out->tile_ms = (float)(tile / nf); out->total_ms = (float)(total / nf);
+    out->ranges_ms = (float)(ranges / nf); out->plan_ms = (float)(plan / nf); out->tile_ms = (float)(tile / nf);
+    out->total_ms = (float)(total / nf);
     out->frames = nf;
     uint32_t c[4];
     VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));

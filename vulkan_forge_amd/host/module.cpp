@@ -205,7 +205,7 @@ public:
         vf_timings tm;
         check(vf_terrain_timings(t, &tm));
         py::dict d;
-        d["ranges_ms"] = tm.ranges_ms; d["tile_ms"] = tm.tile_ms; d["total_ms"] = tm.total_ms;
+        d["ranges_ms"] = tm.ranges_ms; d["plan_ms"] = tm.plan_ms; d["tile_ms"] = tm.tile_ms; d["total_ms"] = tm.total_ms;
         d["blocks_rasterised"] = tm.blocks_rasterised; d["tiles"] = tm.tiles; d["frames"] = tm.frames;
         return d;
     }
