@@ -95,6 +95,7 @@ struct vf_terrain {
     float *d_cap_rad = nullptr;          // per block: capsule radius
     uint2 *d_work = nullptr;             // busy tiles of the frame: (tile, weight), heaviest first
     uint32_t *d_work_count = nullptr;
+    uint32_t *d_last_blocks = nullptr;   // feedback: blocks rasterised per tile in the previous frame (+ [ntiles] = mean)
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint32_t *d_rgba = nullptr;
@@ -258,7 +259,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_row_ranges, t->nb * sizeof(PixelBox));
     A((void **)&t->d_cap_seg, t->nblocks * sizeof(float4));
     A((void **)&t->d_cap_rad, t->nblocks * sizeof(float));
-    A((void **)&t->d_work, (size_t)t->ntx * t->nty * sizeof(uint2));
+    A((void **)&t->d_work, 4 * (size_t)t->ntx * t->nty * sizeof(uint2));       // a tile may be planned as up to 4 strips
+    A((void **)&t->d_last_blocks, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
     A((void **)&t->d_work_count, sizeof(uint32_t));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
@@ -266,6 +268,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
     for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
         for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
     if (err != hipSuccess) {
@@ -288,7 +291,7 @@ void vf_terrain_destroy(vf_terrain *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
-                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_work, t->d_work_count, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
+                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
@@ -352,6 +355,8 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->rank = rank; t->nranks = nranks; t->band_h = band_h;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
     t->rendered = false;
+    // tile numbering changed: forget the scheduling feedback of the previous layout
+    VF_HIP_TRY(hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
     return VF_OK;
 }
 
@@ -422,15 +427,17 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
         VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count);
-        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count);
+        uint32_t *last_mean = t->d_last_blocks + (size_t)t->ntx * t->nty;
+        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count,
+                           t->d_last_blocks, last_mean);
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count, t->d_last_blocks, t->ntx * t->nty, last_mean);
         if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], s));
         if (write_vis)
-            hipLaunchKernelGGL(k_tile<true>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, t->d_vis, stats);
+            hipLaunchKernelGGL(k_tile<true>, dim3(4 * ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
+                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, t->d_vis, stats, t->d_last_blocks);
         else
-            hipLaunchKernelGGL(k_tile<false>, dim3(ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, (uint32_t *)nullptr, stats);
+            hipLaunchKernelGGL(k_tile<false>, dim3(4 * ntiles), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
+                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, t->d_rgba, (uint32_t *)nullptr, stats, t->d_last_blocks);
     }
     if (t->timing) { if (!ntiles) VF_HIP_TRY(hipEventRecord(ev[2], s)); VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipGetLastError());

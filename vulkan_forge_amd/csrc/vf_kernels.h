@@ -485,8 +485,23 @@ __device__ __forceinline__ void tile_rect(const FrameParams &P, uint32_t tile, i
     py_lo = (int32_t)global_row(P, lty * kTileH); py_hi = min(py_lo + kTileH, (int32_t)P.H) - 1;   // band_h is a multiple of kTileH
 }
 
+// work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2 or 4 column strips, each its own workgroup
+__device__ __forceinline__ uint32_t work_tile(uint32_t code) { return code & 0xFFFFFu; }
+__device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_t &px_hi)
+{
+    const uint32_t lg = (code >> 24) & 3u, part = (code >> 20) & 15u;
+    const int32_t w = kTileW >> lg;
+    const int32_t lo = px_lo + (int32_t)part * w;
+    px_hi = min(px_hi, lo + w - 1);
+    px_lo = lo;
+}
+
+// Weights are FEEDBACK: the number of blocks k_tile actually rasterised for the tile in the previous frame (0 on the
+// first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
+// never the result, so a stale value after a camera jump costs time, not correctness.
 __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ rgba,
-                                              uint32_t *__restrict__ vis_out, uint2 *__restrict__ work, uint32_t *__restrict__ work_count)
+                                              uint32_t *__restrict__ vis_out, uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
+                                              const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean)
 {
     __shared__ uint32_t s_hits;
     int32_t px_lo, px_hi, py_lo, py_hi;
@@ -504,7 +519,15 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     __syncthreads();
     const uint32_t total = s_hits;
     if (total) {
-        if (threadIdx.x == 0) work[atomicAdd(work_count, 1u)] = make_uint2(blockIdx.x, total);
+        if (threadIdx.x == 0) {
+            const uint32_t seen = last_blocks[blockIdx.x], mean = *last_mean;
+            const uint32_t weight = seen ? seen : total;
+            uint32_t lg = 0;                                          // strips: 1, 2 or 4
+            if (mean && 2u * seen > (uint32_t)VF_SPLIT2_X2 * mean && px_hi - px_lo + 1 == kTileW) lg = 2u * seen > (uint32_t)VF_SPLIT4_X2 * mean ? 2u : 1u;
+            const uint32_t parts = 1u << lg;
+            const uint32_t at = atomicAdd(work_count, parts);
+            for (uint32_t p = 0; p < parts; ++p) work[at + p] = make_uint2(blockIdx.x | (p << 20) | (lg << 24), weight >> lg);
+        }
         return;
     }
     // background tile: clear colour (src/terrain/mod.rs:421), one row segment per wave-instruction
@@ -517,21 +540,39 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     }
 }
 
-// single workgroup: order the busy tiles by descending weight (bitonic sort in LDS, up to 65536 tiles in passes of 4096;
-// beyond one LDS load the order is only approximately global, which is all the scheduler needs)
-__global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count)
+// single workgroup: order the work items by descending weight (bitonic sort in LDS over the next power of two; lists
+// longer than 4096 are sorted in independent 4096-item runs, which is all the scheduler needs), publish the mean
+// block count per busy tile for the next frame's split decision, and clear the per-tile feedback counters.
+__global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
+                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles, uint32_t *__restrict__ last_mean)
 {
     __shared__ uint2 s[4096];
+    __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_busy;
     const uint32_t n = *work_count;
+    if (threadIdx.x == 0) { s_sum = 0ull; s_busy = 0u; }
+    __syncthreads();
+    // mean of last frame's block counts over the tiles that had any (before they are overwritten by this frame)
+    {
+        unsigned long long sum = 0; uint32_t busy = 0;
+        for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) { const uint32_t b = last_blocks[k]; sum += b; busy += b ? 1u : 0u; }
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); busy += __shfl_xor(busy, o); }
+        if ((threadIdx.x & 63u) == 0) { atomicAdd(&s_sum, sum); atomicAdd(&s_busy, busy); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)(s_sum / s_busy) : 0u;
+    for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // k_tile adds this frame's counts
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
-        for (uint32_t k = threadIdx.x; k < 4096; k += 1024) s[k] = k < m ? work[base + k] : make_uint2(0xFFFFFFFFu, 0u);
+        uint32_t cap = 2;
+        while (cap < m) cap <<= 1;
+        for (uint32_t k = threadIdx.x; k < cap; k += 1024) s[k] = k < m ? work[base + k] : make_uint2(0xFFFFFFFFu, 0u);
         __syncthreads();
-        for (uint32_t size = 2; size <= 4096; size <<= 1)
+        for (uint32_t size = 2; size <= cap; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (uint32_t k = threadIdx.x; k < 2048; k += 1024) {
+                for (uint32_t k = threadIdx.x; k < cap / 2; k += 1024) {
                     const uint32_t lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
-                    const bool desc = (lo & size) == 0;              // descending blocks first
+                    const bool desc = (lo & size) == 0 || size == cap;
                     const uint2 a = s[lo], b = s[hi];
                     const bool swap = desc ? (a.y < b.y) : (a.y > b.y);
                     if (swap) { s[lo] = b; s[hi] = a; }
@@ -560,9 +601,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
                                                        const uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
-                                                       uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats)
+                                                       uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
+                                                       uint32_t *__restrict__ last_blocks)
 {
-    if (blockIdx.x >= *work_count) return;                 // the launch covers every owned tile; only the busy ones have work
+    if (blockIdx.x >= *work_count) return;                 // the launch covers the worst case; only the planned items have work
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -591,11 +633,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t t_start = stats ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock, diagnostics only
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
-    const uint32_t tile = work[blockIdx.x].x;
+    const uint32_t item = work[blockIdx.x].x;
+    const uint32_t tile = work_tile(item);
     uint32_t lty;
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
     tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi, lty);
+    work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2 or 4 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
@@ -828,10 +872,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         if (all >= tile_pixels) break;                                 // uniform: the whole tile is final
     }
     __syncthreads();
+    if (tid == 0) atomicAdd(&last_blocks[tile], s_blocks);   // feedback for the next frame's plan
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
-        stats[4 + 3 * tile] = s_blocks;
-        stats[5 + 3 * tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // raster phase, 10 ns ticks
+        atomicAdd(&stats[4 + 3 * tile], s_blocks);
+        atomicMax(&stats[5 + 3 * tile], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start));   // raster phase, 10 ns ticks
     }
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
@@ -845,7 +890,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
-    if (stats && tid == 0) stats[6 + 3 * tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);   // + fragment phase
+    if (stats && tid == 0) atomicMax(&stats[6 + 3 * tile], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start));   // + fragment phase
 }
 
 // ---------------------------------------------------------------------------------------------
