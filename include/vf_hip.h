@@ -145,6 +145,28 @@ int vf_grid_generate_device(vf_ctx *ctx, uint32_t nx, uint32_t nz, float dx, flo
  * white clear, one colour-varying triangle, tightly packed (H,W,4) u8 into host memory. */
 int vf_triangle_render(vf_ctx *ctx, uint32_t width, uint32_t height, uint8_t *rgba_host);
 
+/* ---- Renderer DEM path ------------------------------------------------- */
+/* HBM-resident heightmap of Renderer::add_terrain and its statistics / normalisation / R32F texture
+ * round trip (src/lib.rs:336-682, 905-951; src/renderer.rs; src/terrain_stats.rs).  Not connected to any draw in
+ * the reference either. */
+typedef struct vf_dem vf_dem;
+int vf_dem_create(vf_ctx *ctx, vf_dem **out);
+void vf_dem_destroy(vf_dem *d);
+/* add_terrain ingest (src/lib.rs:351-388): heights = (f32)src * exaggeration, row-major h rows x w cols */
+int vf_dem_set_heights_f32(vf_dem *d, const float *host, uint32_t w, uint32_t h, float exaggeration);
+int vf_dem_set_heights_f64(vf_dem *d, const double *host, uint32_t w, uint32_t h, float exaggeration);
+/* terrain_stats -> dem_stats_from_slice (src/lib.rs:905-932): out = {min, max, mean, std} */
+int vf_dem_stats(vf_dem *d, float out[4]);
+/* terrain_stats::min_max(data, clamp=true) (src/terrain_stats.rs:11-35): 1st / 99th percentile, stride-sampled above 65536 */
+int vf_dem_percentile_range(vf_dem *d, float *p1, float *p99);
+/* normalize_terrain -> normalize_in_place (src/lib.rs:934-951): mode 0 = minmax to [lo, hi], 1 = zscore */
+int vf_dem_normalize(vf_dem *d, int mode, float lo, float hi, float eps);
+/* upload_height_r32f (src/lib.rs:496-571): heights -> R32F texture (device copy, no row padding) */
+int vf_dem_upload_height(vf_dem *d);
+int vf_dem_texture_size(const vf_dem *d, uint32_t *w, uint32_t *h);   /* 0 x 0 before the first upload */
+/* debug_read_height_patch (src/lib.rs:574-666): texture sub-rectangle -> dst (h rows x w cols) */
+int vf_dem_read_patch(vf_dem *d, uint32_t x, uint32_t y, uint32_t w, uint32_t h, float *dst);
+
 /* ---- multi-GPU helper --------------------------------------------------------------------- */
 /* De-interleave a rank-major gather buffer [nranks][local_rows][W][4] into the final (H,W,4)
  * image on the device (used after an RCCL all-gather/gather when receiving in place is not

@@ -67,6 +67,11 @@ def _load() -> C.CDLL:
                                        _u8p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u32p, C.c_int]
     lib.vfo_render_triangle.argtypes = [C.c_uint32, C.c_uint32, _u8p]
     lib.vfo_raster_triangles.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+    lib.vfo_dem_ingest_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float]
+    lib.vfo_dem_ingest_f64.argtypes = [C.POINTER(C.c_double), _f32p, C.c_size_t, C.c_float]
+    lib.vfo_dem_stats.argtypes = [_f32p, C.c_size_t, _f32p]
+    lib.vfo_dem_normalize.argtypes = [_f32p, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_float, _f32p]
+    lib.vfo_dem_percentile_range.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
     return lib
 
 
@@ -217,6 +222,40 @@ def raster_triangles(clip_xyzw, W, H):
     if lib().vfo_raster_triangles(_p(v, _f32p), v.shape[0], W, H, _p(vis, _u32p)) != 0:
         raise MemoryError("oracle allocation failed")
     return vis
+
+
+def dem_ingest(heightmap, exaggeration):
+    a = np.ascontiguousarray(heightmap)
+    out = np.empty(a.shape, np.float32)
+    if a.dtype == np.float32:
+        lib().vfo_dem_ingest_f32(_p(a, _f32p), _p(out, _f32p), a.size, exaggeration)
+    elif a.dtype == np.float64:
+        lib().vfo_dem_ingest_f64(a.ctypes.data_as(C.POINTER(C.c_double)), _p(out, _f32p), a.size, exaggeration)
+    else:
+        raise TypeError("float32 or float64")
+    return out
+
+
+def dem_stats(heights):
+    h = np.ascontiguousarray(heights, dtype=np.float32)
+    out = np.empty(4, np.float32)
+    lib().vfo_dem_stats(_p(h, _f32p), h.size, _p(out, _f32p))
+    return tuple(float(v) for v in out)
+
+
+def dem_normalize(heights, mode, eps=1e-8, out_range=(0.0, 1.0)):
+    h = np.array(heights, dtype=np.float32, order="C")
+    st = np.array(dem_stats(h), np.float32)
+    lib().vfo_dem_normalize(_p(h, _f32p), h.size, 1 if mode == "zscore" else 0, eps, out_range[0], out_range[1], _p(st, _f32p))
+    return h
+
+
+def dem_percentile_range(heights):
+    h = np.ascontiguousarray(heights, dtype=np.float32)
+    p1, p99 = C.c_float(), C.c_float()
+    if lib().vfo_dem_percentile_range(_p(h, _f32p), h.size, C.byref(p1), C.byref(p99)) != 0:
+        raise MemoryError
+    return p1.value, p99.value
 
 
 def max_threads():

@@ -800,6 +800,58 @@ VFO_API int vfo_raster_triangles(const float *clip_xyzw, uint32_t ntris, uint32_
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Renderer DEM path, sequential f32 loops exactly as the reference writes them.
+ * ---------------------------------------------------------------------------------------- */
+/* add_terrain ingest, src/lib.rs:351-388 */
+VFO_API void vfo_dem_ingest_f32(const float *src, float *dst, size_t n, float exaggeration)
+{
+    for (size_t k = 0; k < n; ++k) dst[k] = src[k] * exaggeration;
+}
+VFO_API void vfo_dem_ingest_f64(const double *src, float *dst, size_t n, float exaggeration)
+{
+    for (size_t k = 0; k < n; ++k) dst[k] = (float)src[k] * exaggeration;
+}
+/* dem_stats_from_slice, src/lib.rs:905-932: out = {min, max, mean, std} */
+VFO_API void vfo_dem_stats(const float *h, size_t n, float out[4])
+{
+    if (n == 0) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    float mn = h[0], mx = h[0], sum = 0.0f;
+    for (size_t k = 0; k < n; ++k) { if (h[k] < mn) mn = h[k]; if (h[k] > mx) mx = h[k]; sum += h[k]; }
+    float mean = sum / (float)n;
+    float vs = 0.0f;
+    for (size_t k = 0; k < n; ++k) { float d = h[k] - mean; vs += d * d; }
+    out[0] = mn; out[1] = mx; out[2] = mean; out[3] = sqrtf(vs / (float)n);
+}
+/* normalize_in_place, src/lib.rs:934-951; stats = {min,max,mean,std} */
+VFO_API void vfo_dem_normalize(float *h, size_t n, int zscore, float eps, float lo, float hi, const float stats[4])
+{
+    if (!zscore) {
+        float denom = fmaxf(fabsf(stats[1] - stats[0]), eps);
+        float scale = (hi - lo) / denom;
+        for (size_t k = 0; k < n; ++k) h[k] = (h[k] - stats[0]) * scale + lo;
+    } else {
+        float denom = fmaxf(stats[3], eps);
+        for (size_t k = 0; k < n; ++k) h[k] = (h[k] - stats[2]) / denom;
+    }
+}
+/* terrain_stats::min_max(data, clamp = true), src/terrain_stats.rs:11-35 */
+static int cmp_f32(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+VFO_API int vfo_dem_percentile_range(const float *h, size_t n, float *p1, float *p99)
+{
+    const size_t SAMPLE = 65536;
+    size_t step = n > SAMPLE ? n / SAMPLE : 1;
+    size_t m = (n + step - 1) / step;
+    float *buf = (float *)malloc(m * sizeof(float));
+    if (!buf) return -1;
+    for (size_t k = 0; k < m; ++k) buf[k] = h[k * step];
+    qsort(buf, m, sizeof(float), cmp_f32);
+    *p1 = buf[(size_t)((float)m * 0.01f)];
+    *p99 = buf[(size_t)((float)m * 0.99f)];
+    free(buf);
+    return 0;
+}
+
 VFO_API int vfo_max_threads(void)
 {
 #ifdef _OPENMP

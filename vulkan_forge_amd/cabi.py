@@ -22,6 +22,8 @@ SYMBOLS = [
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_tile_stats", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device",
+    "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
+    "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
 ]
 
 
@@ -64,6 +66,16 @@ _PROTOS = {
     "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
     "vf_stitch_bands_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    "vf_dem_create": (_i, [_vp, C.POINTER(_vp)]),
+    "vf_dem_destroy": (None, [_vp]),
+    "vf_dem_set_heights_f32": (_i, [_vp, _vp, _u32, _u32, _f]),
+    "vf_dem_set_heights_f64": (_i, [_vp, _vp, _u32, _u32, _f]),
+    "vf_dem_stats": (_i, [_vp, _vp]),
+    "vf_dem_percentile_range": (_i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
+    "vf_dem_normalize": (_i, [_vp, _i, _f, _f, _f]),
+    "vf_dem_upload_height": (_i, [_vp]),
+    "vf_dem_texture_size": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
+    "vf_dem_read_patch": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),
 }
 
 

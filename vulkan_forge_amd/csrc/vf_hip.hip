@@ -3,7 +3,9 @@
 #include "../../include/vf_hip.h"
 #include "vf_kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -596,6 +598,216 @@ int vf_triangle_render(vf_ctx *ctx, uint32_t width, uint32_t height, uint8_t *rg
     if (err == hipSuccess) err = hipMemcpy(rgba_host, d, npx * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (err != hipSuccess) return fail(VF_ERR_HIP, std::string("triangle render failed: ") + hipGetErrorString(err));
+    return VF_OK;
+}
+
+// ---- Renderer DEM path -------------------------------------------------------------------------------------
+} // extern "C"   (struct definition below is C++)
+
+struct vf_dem {
+    vf_ctx *ctx = nullptr;
+    float *d_h = nullptr;        // heights (already multiplied by the exaggeration), w*h
+    float *d_tex = nullptr;      // R32F "texture" written by upload_height_r32f
+    void *d_stage = nullptr;     // staging for the ingest (raw f32 / f64 samples)
+    size_t stage_bytes = 0;
+    uint32_t w = 0, h = 0, tex_w = 0, tex_h = 0;
+    size_t cap = 0, tex_cap = 0;
+    uint32_t *d_mm = nullptr;    // min / max as ordered ints
+    double *d_partial = nullptr; // one partial sum per reduction block
+};
+static constexpr int kDemBlocks = 2048;
+
+extern "C" {
+
+int vf_dem_create(vf_ctx *ctx, vf_dem **out)
+{
+    if (!ctx || !out) return fail(VF_ERR_INVALID, "NULL argument");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    vf_dem *d = new (std::nothrow) vf_dem;
+    if (!d) return fail(VF_ERR_NOMEM, "out of host memory");
+    d->ctx = ctx;
+    hipError_t e = hipMalloc(&d->d_mm, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d->d_partial, kDemBlocks * sizeof(double));
+    if (e != hipSuccess) { vf_dem_destroy(d); return fail(VF_ERR_NOMEM, std::string("dem allocation failed: ") + hipGetErrorString(e)); }
+    *out = d;
+    return VF_OK;
+}
+
+void vf_dem_destroy(vf_dem *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = { d->d_h, d->d_tex, d->d_stage, d->d_mm, d->d_partial };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete d;
+}
+
+} // extern "C"
+
+template <typename T>
+static int dem_ingest(vf_dem *d, const T *host, uint32_t w, uint32_t h, float exaggeration)
+{
+    if (!d || !host) return fail(VF_ERR_INVALID, "NULL argument");
+    if (w == 0 || h == 0) return fail(VF_ERR_INVALID, "heightmap cannot be empty");
+    VF_HIP_TRY(hipSetDevice(d->ctx->device));
+    const size_t n = (size_t)w * h;
+    if (n > d->cap) {
+        if (d->d_h) VF_HIP_TRY(hipFree(d->d_h));
+        d->d_h = nullptr; d->cap = 0;
+        VF_HIP_TRY(hipMalloc(&d->d_h, n * sizeof(float)));
+        d->cap = n;
+    }
+    if (n * sizeof(T) > d->stage_bytes) {
+        if (d->d_stage) VF_HIP_TRY(hipFree(d->d_stage));
+        d->d_stage = nullptr; d->stage_bytes = 0;
+        VF_HIP_TRY(hipMalloc(&d->d_stage, n * sizeof(T)));
+        d->stage_bytes = n * sizeof(T);
+    }
+    hipStream_t s = d->ctx->stream;
+    VF_HIP_TRY(hipMemcpyAsync(d->d_stage, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_dem_ingest<T>, dim3(blocks), dim3(256), 0, s, (const T *)d->d_stage, d->d_h, n, exaggeration);
+    VF_HIP_TRY(hipGetLastError());
+    VF_HIP_TRY(hipStreamSynchronize(s));     // the host buffer is only borrowed for this call
+    d->w = w; d->h = h;
+    return VF_OK;
+}
+
+extern "C" {
+
+int vf_dem_set_heights_f32(vf_dem *d, const float *host, uint32_t w, uint32_t h, float ex) { return dem_ingest<float>(d, host, w, h, ex); }
+int vf_dem_set_heights_f64(vf_dem *d, const double *host, uint32_t w, uint32_t h, float ex) { return dem_ingest<double>(d, host, w, h, ex); }
+
+static int dem_stats_impl(vf_dem *d, float out[4])
+{
+    if (!d->d_h || d->w == 0) return fail(VF_ERR_INVALID, "no terrain uploaded; call add_terrain() first");
+    VF_HIP_TRY(hipSetDevice(d->ctx->device));
+    const size_t n = (size_t)d->w * d->h;
+    hipStream_t s = d->ctx->stream;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)kDemBlocks);
+    const uint32_t init[2] = { 0xFFFFFFFFu, 0u };
+    VF_HIP_TRY(hipMemcpyAsync(d->d_mm, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_dem_minmaxsum, dim3(blocks), dim3(256), 0, s, d->d_h, n, d->d_mm, d->d_partial);
+    VF_HIP_TRY(hipGetLastError());
+    std::vector<double> part(blocks);
+    uint32_t mm[2];
+    VF_HIP_TRY(hipMemcpyAsync(part.data(), d->d_partial, blocks * sizeof(double), hipMemcpyDeviceToHost, s));
+    VF_HIP_TRY(hipMemcpyAsync(mm, d->d_mm, sizeof mm, hipMemcpyDeviceToHost, s));
+    VF_HIP_TRY(hipStreamSynchronize(s));
+    double sum = 0.0;
+    for (double v : part) sum += v;
+    const float mean = (float)(sum / (double)n);
+    hipLaunchKernelGGL(k_dem_sqdev, dim3(blocks), dim3(256), 0, s, d->d_h, n, mean, d->d_partial);
+    VF_HIP_TRY(hipGetLastError());
+    VF_HIP_TRY(hipMemcpyAsync(part.data(), d->d_partial, blocks * sizeof(double), hipMemcpyDeviceToHost, s));
+    VF_HIP_TRY(hipStreamSynchronize(s));
+    double var = 0.0;
+    for (double v : part) var += v;
+    auto unorder = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
+    // an all-NaN map leaves the init pattern; the reference would report its first element (NaN)
+    out[0] = mm[0] == 0xFFFFFFFFu ? NAN : unorder(mm[0]);
+    out[1] = mm[1] == 0u ? NAN : unorder(mm[1]);
+    out[2] = mean;
+    out[3] = std::sqrt((float)(var / (double)n));
+    return VF_OK;
+}
+int vf_dem_stats(vf_dem *d, float out[4])
+{
+    if (!d || !out) return fail(VF_ERR_INVALID, "NULL argument");
+    return dem_stats_impl(d, out);
+}
+
+int vf_dem_percentile_range(vf_dem *d, float *p1, float *p99)
+{
+    if (!d || !p1 || !p99) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!d->d_h || d->w == 0) return fail(VF_ERR_INVALID, "no terrain uploaded; call add_terrain() first");
+    VF_HIP_TRY(hipSetDevice(d->ctx->device));
+    const size_t n = (size_t)d->w * d->h, SAMPLE = 65536;
+    const size_t step = n > SAMPLE ? n / SAMPLE : 1;                 // src/terrain_stats.rs:24-29
+    const size_t m = (n + step - 1) / step;                          // iter().step_by(step).count()
+    std::vector<float> buf(m);
+    hipStream_t s = d->ctx->stream;
+    if (step == 1) {
+        VF_HIP_TRY(hipMemcpyAsync(buf.data(), d->d_h, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    } else {
+        if (m * sizeof(float) > d->stage_bytes) {
+            if (d->d_stage) VF_HIP_TRY(hipFree(d->d_stage));
+            d->d_stage = nullptr; d->stage_bytes = 0;
+            VF_HIP_TRY(hipMalloc(&d->d_stage, m * sizeof(float)));
+            d->stage_bytes = m * sizeof(float);
+        }
+        hipLaunchKernelGGL(k_dem_sample, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d->d_h, n, step, (float *)d->d_stage, m);
+        VF_HIP_TRY(hipGetLastError());
+        VF_HIP_TRY(hipMemcpyAsync(buf.data(), d->d_stage, m * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    VF_HIP_TRY(hipStreamSynchronize(s));
+    // the sample is at most ~131071 values: ordering it is host logic, exactly like the reference's sort_by
+    std::stable_sort(buf.begin(), buf.end(), [](float a, float b) { return a < b; });
+    *p1 = buf[(size_t)((float)buf.size() * 0.01f)];
+    *p99 = buf[(size_t)((float)buf.size() * 0.99f)];
+    return VF_OK;
+}
+
+int vf_dem_normalize(vf_dem *d, int mode, float lo, float hi, float eps)
+{
+    if (!d) return fail(VF_ERR_INVALID, "NULL argument");
+    if (mode != 0 && mode != 1) return fail(VF_ERR_INVALID, "mode must be 'minmax' or 'zscore'");
+    float st[4];
+    int rc = dem_stats_impl(d, st);
+    if (rc != VF_OK) return rc;
+    const size_t n = (size_t)d->w * d->h;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipStream_t s = d->ctx->stream;
+    if (mode == 0) {
+        const float denom = std::fmax(std::fabs(st[1] - st[0]), eps);    // src/lib.rs:938-939
+        const float scale = (hi - lo) / denom;
+        hipLaunchKernelGGL(k_dem_normalize, dim3(blocks), dim3(256), 0, s, d->d_h, n, 0, st[0], scale, lo);
+    } else {
+        const float denom = std::fmax(st[3], eps);                       // :945
+        hipLaunchKernelGGL(k_dem_normalize, dim3(blocks), dim3(256), 0, s, d->d_h, n, 1, st[2], denom, 0.0f);
+    }
+    VF_HIP_TRY(hipGetLastError());
+    VF_HIP_TRY(hipStreamSynchronize(s));
+    return VF_OK;
+}
+
+int vf_dem_upload_height(vf_dem *d)
+{
+    if (!d) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!d->d_h || d->w == 0) return fail(VF_ERR_INVALID, "no terrain uploaded; call add_terrain() first");
+    VF_HIP_TRY(hipSetDevice(d->ctx->device));
+    const size_t n = (size_t)d->w * d->h;
+    if (n > d->tex_cap) {
+        if (d->d_tex) VF_HIP_TRY(hipFree(d->d_tex));
+        d->d_tex = nullptr; d->tex_cap = 0;
+        VF_HIP_TRY(hipMalloc(&d->d_tex, n * sizeof(float)));
+        d->tex_cap = n;
+    }
+    VF_HIP_TRY(hipMemcpyAsync(d->d_tex, d->d_h, n * sizeof(float), hipMemcpyDeviceToDevice, d->ctx->stream));
+    VF_HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+    d->tex_w = d->w; d->tex_h = d->h;
+    return VF_OK;
+}
+
+int vf_dem_texture_size(const vf_dem *d, uint32_t *w, uint32_t *h)
+{
+    if (!d || !w || !h) return fail(VF_ERR_INVALID, "NULL argument");
+    *w = d->tex_w; *h = d->tex_h;
+    return VF_OK;
+}
+
+int vf_dem_read_patch(vf_dem *d, uint32_t x, uint32_t y, uint32_t w, uint32_t h, float *dst)
+{
+    if (!d || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (w == 0 || h == 0) return fail(VF_ERR_INVALID, "patch dimensions must be > 0");
+    if (!d->d_tex) return fail(VF_ERR_INVALID, "no height texture uploaded; call upload_height_r32f() first");
+    if ((uint64_t)x + w > d->tex_w)
+        return fail(VF_ERR_INVALID, "requested patch exceeds texture bounds in x: x+w (" + std::to_string((uint64_t)x + w) + ") > width (" + std::to_string(d->tex_w) + ")");
+    if ((uint64_t)y + h > d->tex_h)
+        return fail(VF_ERR_INVALID, "requested patch exceeds texture bounds in y: y+h (" + std::to_string((uint64_t)y + h) + ") > height (" + std::to_string(d->tex_h) + ")");
+    VF_HIP_TRY(hipSetDevice(d->ctx->device));
+    VF_HIP_TRY(hipMemcpy2D(dst, (size_t)w * 4, d->d_tex + (size_t)y * d->tex_w + x, (size_t)d->tex_w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost));
     return VF_OK;
 }
 

@@ -950,6 +950,77 @@ __global__ __launch_bounds__(256) void k_triangle(uint32_t W, uint32_t H, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Renderer DEM path: add_terrain / terrain_stats / normalize_terrain on HBM-resident heights.
+// All four kernels are streaming and HBM-bound (4 B read [+ 4 B written] per sample).
+// ---------------------------------------------------------------------------------------------
+// add_terrain ingest (src/lib.rs:351-388): heights[k] = (f32)src[k] * exaggeration
+template <typename T>
+__global__ void k_dem_ingest(const T *__restrict__ src, float *__restrict__ dst, size_t n, float exaggeration)
+{
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        dst[k] = (float)src[k] * exaggeration;
+}
+
+// pass 1 of dem_stats_from_slice (src/lib.rs:905-932): min, max, sum.  The reference adds in f32 in index order; a
+// parallel sum cannot reproduce that rounding, so the sum is carried in FP64 (closer to the true mean) -- DESIGN.md.
+// out: [0] min bits (ordered-int trick), [1] max bits, then one double per block in `partial`.
+__device__ __forceinline__ uint32_t float_order(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float float_unorder(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ __launch_bounds__(256) void k_dem_minmaxsum(const float *__restrict__ h, size_t n, uint32_t *__restrict__ mm, double *__restrict__ partial)
+{
+    __shared__ double s_sum[4];
+    __shared__ uint32_t s_lo[4], s_hi[4];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    double sum = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const float v = h[k];
+        const uint32_t o = float_order(v);
+        if (v == v) { lo = min(lo, o); hi = max(hi, o); }     // NaN never wins a `<` / `>` comparison in the reference loop either
+        sum += (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+        sum += __shfl_xor(sum, o);
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_sum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&mm[0], min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])));
+        atomicMax(&mm[1], max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
+        partial[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    }
+}
+// pass 2: sum of squared deviations from the (f32) mean, as the reference forms them: diff = h - mean (f32), diff*diff
+__global__ __launch_bounds__(256) void k_dem_sqdev(const float *__restrict__ h, size_t n, float mean, double *__restrict__ partial)
+{
+    __shared__ double s_sum[4];
+    double sum = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) {
+        const float d = h[k] - mean;
+        sum += (double)(d * d);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+}
+// normalize_in_place (src/lib.rs:934-951): v = (v - a) * scale + lo   |   v = (v - a) / denom
+__global__ void k_dem_normalize(float *__restrict__ h, size_t n, int zscore, float a, float scale_or_denom, float lo)
+{
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const float v = h[k];
+        h[k] = zscore ? (v - a) / scale_or_denom : (v - a) * scale_or_denom + lo;
+    }
+}
+// stride sample for the 1-99 percentile clamp of terrain_stats::min_max (src/terrain_stats.rs:24-29)
+__global__ void k_dem_sample(const float *__restrict__ h, size_t n, size_t step, float *__restrict__ out, size_t nout)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nout && k * step < n) out[k] = h[k * step];
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-GPU: [nranks][local_rows][W] rank-major gather buffer -> (H, W) image
 // ---------------------------------------------------------------------------------------------
 __global__ void k_stitch_bands(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t row_vec4, uint32_t H,

@@ -243,10 +243,13 @@ public:
     Scene(uint32_t w, uint32_t h, py::object grid, py::object colormap) : TerrainObject(1, w, h, grid, colormap) {}
 };
 
-// ---- Renderer: the triangle smoke path (src/lib.rs:245-334, 685-721) ---------------------------------
+// ---- Renderer: the triangle smoke path (src/lib.rs:245-334, 685-721) + the DEM path (:336-682) ---------------------
 class Renderer {
 public:
     Renderer(uint32_t w, uint32_t h) : W(w), H(h) { global_ctx(); }
+    ~Renderer() { if (dem) vf_dem_destroy(dem); }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
     std::string info() const { return "Renderer " + std::to_string(W) + "x" + std::to_string(H) + ", format=Rgba8UnormSrgb"; }
     py::array_t<uint8_t> render_triangle_rgba()
     {
@@ -260,8 +263,96 @@ public:
         check(vf_triangle_render(global_ctx(), W, H, px.data()));
         write_png_rgba8(path, px.data(), W, H);
     }
+
+    // add_terrain, src/lib.rs:336-421
+    void add_terrain(py::object heightmap, std::tuple<float, float> spacing, float exaggeration, const std::string &colormap)
+    {
+        if (std::get<0>(spacing) <= 0.0f || std::get<1>(spacing) <= 0.0f) throw std::runtime_error("spacing components must be > 0");
+        if (exaggeration <= 0.0f) throw std::runtime_error("exaggeration must be > 0");
+        const char *kind = "heightmap must be a 2-D NumPy array of dtype float32 or float64";
+        if (!py::isinstance<py::array>(heightmap)) throw std::runtime_error(kind);
+        py::array arr = py::reinterpret_borrow<py::array>(heightmap);
+        const bool f32 = arr.dtype().is(py::dtype::of<float>()), f64 = arr.dtype().is(py::dtype::of<double>());
+        if (arr.ndim() != 2 || !(f32 || f64)) throw std::runtime_error(kind);
+        if (!(arr.flags() & py::array::c_style)) throw std::runtime_error("heightmap must be C-contiguous (row-major)");
+        const uint32_t h = (uint32_t)arr.shape(0), w = (uint32_t)arr.shape(1);
+        if (w == 0 || h == 0) throw std::runtime_error("heightmap cannot be empty");
+        if (!dem) check(vf_dem_create(global_ctx(), &dem));
+        if (f32) check(vf_dem_set_heights_f32(dem, static_cast<const float *>(arr.data()), w, h, exaggeration));
+        else check(vf_dem_set_heights_f64(dem, static_cast<const double *>(arr.data()), w, h, exaggeration));
+        has_terrain = true;
+        // TerrainMeta::compute_and_store_h_range (src/renderer.rs:26-30): 1-99 percentile clamp
+        float p1 = 0, p99 = 1;
+        check(vf_dem_percentile_range(dem, &p1, &p99));
+        h_min = p1; h_max = std::fmax(p99, p1 + 1e-5f);
+        bool known = false;
+        for (const char *s : kSupported) known |= colormap == s;
+        if (!known) throw std::runtime_error(unknown_colormap(colormap));    // after the range, like the reference (:398-407)
+        terrain_colormap = colormap;
+    }
+    void need_terrain() const { if (!has_terrain) throw std::runtime_error("no terrain uploaded; call add_terrain() first"); }
+    std::tuple<float, float, float, float> terrain_stats()                  // src/lib.rs:423-429
+    {
+        need_terrain();
+        float st[4];
+        check(vf_dem_stats(dem, st));
+        return { st[0], st[1], st[2], st[3] };
+    }
+    void set_height_range(float mn, float mx)                               // src/renderer.rs:32-42
+    {
+        if (!std::isfinite(mn) || !std::isfinite(mx)) throw py::value_error("min/max must be finite floats");
+        if (mn >= mx) throw py::value_error("min must be < max");
+        h_min = mn; h_max = mx;
+    }
+    void set_sun(float elevation_deg, float azimuth_deg)                    // src/lib.rs:441-462
+    {
+        if (!std::isfinite(elevation_deg) || !std::isfinite(azimuth_deg)) throw py::value_error("angles must be finite");
+        const float k = 3.14159265358979323846f / 180.0f;
+        const float el = elevation_deg * k, az = azimuth_deg * k;
+        globals.sun_dir = normalize_or_zero({ std::cos(el) * std::cos(az), std::sin(el), std::cos(el) * std::sin(az) });
+    }
+    void set_exposure(float exposure)                                       // src/lib.rs:464-473
+    {
+        if (!std::isfinite(exposure) || exposure <= 0.0f) throw py::value_error("exposure must be > 0");
+        globals.exposure = exposure;
+    }
+    void normalize_terrain(const std::string &mode, py::object range, py::object eps)   // src/lib.rs:476-493
+    {
+        need_terrain();
+        std::string m = mode;
+        for (auto &c : m) c = (char)std::tolower((unsigned char)c);
+        int code = m == "minmax" ? 0 : (m == "zscore" ? 1 : -1);
+        if (code < 0) throw std::runtime_error("mode must be 'minmax' or 'zscore'");
+        float e = eps.is_none() ? 1e-8f : eps.cast<float>();
+        std::tuple<float, float> r = range.is_none() ? std::make_tuple(0.0f, 1.0f) : range.cast<std::tuple<float, float>>();
+        check(vf_dem_normalize(dem, code, std::get<0>(r), std::get<1>(r), e));
+    }
+    void upload_height_r32f() { need_terrain(); check(vf_dem_upload_height(dem)); }     // src/lib.rs:495-571
+    py::array_t<float> debug_read_height_patch(uint32_t x, uint32_t y, uint32_t w, uint32_t h)   // :573-666
+    {
+        if (w == 0 || h == 0) throw std::runtime_error("patch dimensions must be > 0");
+        py::array_t<float> out({ (py::ssize_t)h, (py::ssize_t)w });
+        uint32_t tw = 0, th = 0;
+        if (dem) check(vf_dem_texture_size(dem, &tw, &th));
+        if (tw == 0) { std::memset(out.mutable_data(), 0, (size_t)w * h * sizeof(float)); return out; }   // no texture yet: zeros (:580-588)
+        check(vf_dem_read_patch(dem, x, y, w, h, out.mutable_data()));
+        return out;
+    }
+    py::array_t<float> read_full_height_texture()                          // src/lib.rs:668-681
+    {
+        need_terrain();
+        uint32_t tw = 0, th = 0;
+        check(vf_dem_texture_size(dem, &tw, &th));
+        if (tw == 0) throw std::runtime_error("no height texture uploaded; call upload_height_r32f() first");
+        return debug_read_height_patch(0, 0, tw, th);
+    }
 private:
     uint32_t W, H;
+    vf_dem *dem = nullptr;
+    bool has_terrain = false;
+    float h_min = 0.0f, h_max = 1.0f;          // TerrainMeta (src/renderer.rs:7-22)
+    Globals globals;
+    std::string terrain_colormap;
 };
 
 // ---- module functions ------------------------------------------------------------------------------
@@ -401,7 +492,17 @@ PYBIND11_MODULE(_vulkan_forge, m)
         .def(py::init<uint32_t, uint32_t>(), py::arg("width"), py::arg("height"))
         .def("info", &Renderer::info)
         .def("render_triangle_rgba", &Renderer::render_triangle_rgba)
-        .def("render_triangle_png", &Renderer::render_triangle_png, py::arg("path"));
+        .def("render_triangle_png", &Renderer::render_triangle_png, py::arg("path"))
+        .def("add_terrain", &Renderer::add_terrain, py::arg("heightmap"), py::arg("spacing"), py::arg("exaggeration") = 1.0f,
+             py::arg("colormap") = "viridis")
+        .def("terrain_stats", &Renderer::terrain_stats)
+        .def("set_height_range", &Renderer::set_height_range, py::arg("min"), py::arg("max"))
+        .def("set_sun", &Renderer::set_sun, py::arg("elevation_deg"), py::arg("azimuth_deg"))
+        .def("set_exposure", &Renderer::set_exposure, py::arg("exposure"))
+        .def("normalize_terrain", &Renderer::normalize_terrain, py::arg("mode"), py::arg("range") = py::none(), py::arg("eps") = py::none())
+        .def("upload_height_r32f", &Renderer::upload_height_r32f)
+        .def("debug_read_height_patch", &Renderer::debug_read_height_patch, py::arg("x"), py::arg("y"), py::arg("w"), py::arg("h"))
+        .def("read_full_height_texture", &Renderer::read_full_height_texture);
     bind_terrain<TerrainSpike>(m, "TerrainSpike");
     bind_terrain<Scene>(m, "Scene").def("set_height_from_r32f", &Scene::set_height_from_r32f, py::arg("height_r32f"));
     m.def("enumerate_adapters", &enumerate_adapters);
