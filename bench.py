@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--camera", choices=["default", "fill"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fill camera) measurement")
+    ap.add_argument("--check", action="store_true", help="after timing, compare the gathered frame with a single-rank render")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
+                         "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
     return ap.parse_args()
 
 
@@ -79,10 +83,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible", file=sys.stderr)
         sys.exit(1)
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vulkan_forge_amd import cabi, dist as vdist
 
@@ -104,13 +113,26 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
+    host_local = torch.empty((rows, W, 4), dtype=torch.uint8).pin_memory() if (args.rehearse and world > 1) else None
+    host_image = torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() if (args.rehearse and world > 1 and rank == 0) else None
+
     def step():
         t.render(stream)
-        if world > 1:
-            vdist.gather_bands(local, image, H, BAND_H, dst=0)
+        if world > 1 and not args.rehearse:
+            vdist.gather_bands(local, image, H, BAND_H, dst=0)           # RCCL point-to-point, device memory
+        elif world > 1:
+            host_local.copy_(local, non_blocking=False)                  # rehearsal: same exchange over gloo via host memory
+            vdist.gather_bands(host_local, host_image, H, BAND_H, dst=0)
+            if rank == 0:
+                image.copy_(host_image, non_blocking=False)
+
+    SETTLE = 6   # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
+                 # splitting) and needs a few frames of a new camera to converge; results never depend on it
 
     def timed(camera, steps, warmup):
         t.set_uniforms(camera_uniforms(camera, W, H))
+        for _ in range(SETTLE):
+            t.render(stream)
         for _ in range(warmup):
             step()
         if world > 1:
@@ -142,6 +164,25 @@ def main():
         dt2, tm2 = timed(other, max(3, args.steps // 4), 1)
         n2 = max(3, args.steps // 4)
         extra = {"camera": other, "value": W * H * n2 / dt2 / 1e6, "ms_per_step": dt2 / n2 * 1e3, "tile_kernel_ms": tm2["tile_ms"]}
+
+    check = None
+    if args.check:
+        t.set_uniforms(camera_uniforms(args.camera, W, H))
+        step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if rank == 0:
+            got = image.clone()
+            t.set_shard(0, 1, BAND_H)
+            t.set_output_device(image.data_ptr())
+            t.render(stream)
+            torch.cuda.synchronize()
+            check = bool(torch.equal(got, image))
+            t.set_shard(rank, world, BAND_H)
+            t.set_output_device(image.data_ptr() if world == 1 else local.data_ptr())
+        if world > 1:
+            dist.barrier()
 
     # ---- roofline of the dominant kernel (k_tile: vertex + setup + raster + fragment, fused) -------------------
     # algorithmic bytes per launch (whole frame): height texture read once + RGBA8 written once + LUT
@@ -190,6 +231,10 @@ def main():
             "cpu_baseline": cpu,
             "other_camera": extra,
         }
+        if check is not None:
+            out["gathered_frame_equals_single_rank_frame"] = check
+        if args.rehearse:
+            out["rehearsal"] = "gloo via host memory on one GPU; not a performance number"
         print(json.dumps(out), flush=True)
     t.close()
     if world > 1:

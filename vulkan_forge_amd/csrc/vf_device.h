@@ -21,12 +21,9 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #ifndef VF_TILE_THREADS
 #define VF_TILE_THREADS 1024
 #endif
-// strip splitting: a tile whose last-frame block count exceeds VF_SPLIT2_X2/2 (VF_SPLIT4_X2/2) times the mean is cut in 2 (4)
-#ifndef VF_SPLIT2_X2
-#define VF_SPLIT2_X2 6
-#endif
-#ifndef VF_SPLIT4_X2
-#define VF_SPLIT4_X2 16
+// strip splitting quantum, in halves of the even per-item share of last frame's work (tuned on C4: 3 = 1.5 shares)
+#ifndef VF_SPLIT_QUANTUM_X2
+#define VF_SPLIT_QUANTUM_X2 3
 #endif
 #ifndef VF_RESCAN_EVERY
 #define VF_RESCAN_EVERY 2

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64) void k_height_blocks(uint32_t n, uint32_t nb, u
 // and the capsule rejects most of the tiles its bounding box crosses.
 __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
                                                      PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes,
-                                                     float4 *__restrict__ cap_seg, float *__restrict__ cap_rad)
+                                                     float4 *__restrict__ cap_seg, float *__restrict__ cap_rad,
+                                                     uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi)
 {
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
     const uint32_t by = blockIdx.x;
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
         }
         cap_seg[b] = seg; cap_rad[b] = rad;
         if (r.x0 <= r.x1) {
+            // which blocks of this row can reach tile column tc?  [rc_lo, rc_hi) lets the tile kernel test a handful of
+            // blocks per row instead of all nb (arrays are reset to 0xFFFFFFFF / 0 before the launch)
+            for (uint32_t tc = (uint32_t)r.x0 / kTileW; tc <= (uint32_t)r.x1 / kTileW; ++tc) {
+                atomicMin(&rc_lo[by * P.ntx + tc], bx);
+                atomicMax(&rc_hi[by * P.ntx + tc], bx + 1u);
+            }
             atomicMin(&s_rr[0], (int)r.x0); atomicMin(&s_rr[1], (int)r.y0);
             atomicMax(&s_rr[2], (int)r.x1); atomicMax(&s_rr[3], (int)r.y1);
         }
@@ -485,23 +492,28 @@ __device__ __forceinline__ void tile_rect(const FrameParams &P, uint32_t tile, i
     py_lo = (int32_t)global_row(P, lty * kTileH); py_hi = min(py_lo + kTileH, (int32_t)P.H) - 1;   // band_h is a multiple of kTileH
 }
 
-// work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2 or 4 column strips, each its own workgroup
+// work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2, 4, 8 or 16 column strips, each its own
+// workgroup (blocks are only a few pixels wide, so narrow strips share little work)
+constexpr uint32_t kSplitBudget = 2048;                    // extra work items a frame may create by splitting
+constexpr uint32_t kTargetItems = 1024;                    // work items that keep 256 CUs busy (4 per CU)
 __device__ __forceinline__ uint32_t work_tile(uint32_t code) { return code & 0xFFFFFu; }
 __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_t &px_hi)
 {
-    const uint32_t lg = (code >> 24) & 3u, part = (code >> 20) & 15u;
+    const uint32_t lg = (code >> 24) & 7u, part = (code >> 20) & 15u;
     const int32_t w = kTileW >> lg;
     const int32_t lo = px_lo + (int32_t)part * w;
     px_hi = min(px_hi, lo + w - 1);
     px_lo = lo;
 }
 
-// Weights are FEEDBACK: the number of blocks k_tile actually rasterised for the tile in the previous frame (0 on the
-// first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
+// Weights are FEEDBACK: the time (10 ns ticks, summed over its strips) k_tile spent on the tile in the previous frame
+// (0 on the first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
 // never the result, so a stale value after a camera jump costs time, not correctness.
 __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ rgba,
                                               uint32_t *__restrict__ vis_out, uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
-                                              const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean)
+                                              const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
+                                              uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
+                                              const uint32_t *__restrict__ rc_hi)
 {
     __shared__ uint32_t s_hits;
     int32_t px_lo, px_hi, py_lo, py_hi;
@@ -510,9 +522,10 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     if (threadIdx.x == 0) s_hits = 0;
     __syncthreads();
     uint32_t hits = 0;
+    const uint32_t tcol = blockIdx.x % P.ntx;
     for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
         const PixelBox rr = row_boxes[r];
-        hits += (rr.x0 <= rr.x1 && rr.x1 >= px_lo && rr.x0 <= px_hi && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
+        hits += (rc_lo[r * P.ntx + tcol] < rc_hi[r * P.ntx + tcol] && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
     }
     for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
     if ((threadIdx.x & 63u) == 0 && hits) atomicAdd(&s_hits, hits);
@@ -522,8 +535,16 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
         if (threadIdx.x == 0) {
             const uint32_t seen = last_blocks[blockIdx.x], mean = *last_mean;
             const uint32_t weight = seen ? seen : total;
-            uint32_t lg = 0;                                          // strips: 1, 2 or 4
-            if (mean && 2u * seen > (uint32_t)VF_SPLIT2_X2 * mean && px_hi - px_lo + 1 == kTileW) lg = 2u * seen > (uint32_t)VF_SPLIT4_X2 * mean ? 2u : 1u;
+            // strips: 1, 2, 4, 8 or 16.  `mean` holds the split quantum published by k_plan_sort: four times the work one
+            // item would carry if last frame's blocks were spread evenly over kTargetItems workgroups -- so a lightly loaded
+            // GPU (one rank of a multi-GPU frame) cuts its few heavy tiles finer than a fully loaded one.
+            uint32_t lg = 0;
+            if (mean && px_hi - px_lo + 1 == kTileW) {
+                const uint32_t q = seen / mean;
+                lg = q >= 16u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
+                // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer strips
+                while (lg && atomicAdd(split_budget, (1u << lg) - 1u) + (1u << lg) - 1u > kSplitBudget) { atomicSub(split_budget, (1u << lg) - 1u); --lg; }
+            }
             const uint32_t parts = 1u << lg;
             const uint32_t at = atomicAdd(work_count, parts);
             for (uint32_t p = 0; p < parts; ++p) work[at + p] = make_uint2(blockIdx.x | (p << 20) | (lg << 24), weight >> lg);
@@ -560,7 +581,8 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
         if ((threadIdx.x & 63u) == 0) { atomicAdd(&s_sum, sum); atomicAdd(&s_busy, busy); }
     }
     __syncthreads();
-    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)(s_sum / s_busy) : 0u;
+    // split quantum: half of 4x the even share (a tile reaching 2 quanta is cut in two, 4 quanta in four, ...)
+    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X2 * s_sum / (2ull * kTargetItems)) : 0u;
     for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // k_tile adds this frame's counts
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
@@ -601,6 +623,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
                                                        const uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
+                                                       const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
                                                        uint32_t *__restrict__ last_blocks)
 {
@@ -631,7 +654,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     __shared__ float s_thr[256];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t t_start = stats ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock, diagnostics only
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[blockIdx.x].x;
     const uint32_t tile = work_tile(item);
@@ -639,7 +662,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
     tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi, lty);
-    work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2 or 4 column strips
+    const uint32_t tcol = tile % P.ntx;
+    work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2..16 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
@@ -656,7 +680,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         bool hit = false;
         if (r < P.nb) {
             const PixelBox rr = row_boxes[r];
-            hit = rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi && rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
+            hit = rc_lo[r * P.ntx + tcol] < rc_hi[r * P.ntx + tcol] && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi &&
+                  rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0 && m) s_rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
@@ -688,11 +713,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         // ---- chunk set-up 2: each wave tests the blocks of its rows against the tile; ballots are kept for the fill pass ----
         for (uint32_t k = wave; k < nrowsteps; k += kWaves) {
             const uint32_t by = s_steprow[k];
+            const uint32_t bx_lo = rc_lo[by * P.ntx + tcol], bx_hi = rc_hi[by * P.ntx + tcol];   // only these can reach the tile column
             uint32_t cnt = 0;
             for (uint32_t g = 0; g < hit_words; ++g) {
+                if (g * 64u + 63u < bx_lo || g * 64u >= bx_hi) { if (lane == 0) s_hit[k][g] = 0ull; continue; }   // uniform
                 const uint32_t bx = g * 64u + lane;
                 bool hit = false;
-                if (bx < P.nb) {
+                if (bx >= bx_lo && bx < bx_hi) {
                     const uint32_t bidx = by * P.nb + bx;
                     hit = block_is_candidate(boxes[bidx], cap_seg, cap_rad, bidx, T);
                 }
@@ -872,7 +899,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         if (all >= tile_pixels) break;                                 // uniform: the whole tile is final
     }
     __syncthreads();
-    if (tid == 0) atomicAdd(&last_blocks[tile], s_blocks);   // feedback for the next frame's plan
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
         atomicAdd(&stats[4 + 3 * tile], s_blocks);
@@ -890,7 +916,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
-    if (stats && tid == 0) atomicMax(&stats[6 + 3 * tile], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start));   // + fragment phase
+    if (tid == 0) {
+        const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
+        atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
+        if (stats) atomicMax(&stats[6 + 3 * tile], ticks);    // raster + fragment phase
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
