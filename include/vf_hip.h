@@ -129,6 +129,10 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 /* diagnostics (timing enabled): per launched tile of the last frame, 3 words: candidate blocks processed,
  * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock) */
 int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles);
+/* diagnostics, only in libraries built with -DVF_PHASE_PROF (VF_ERR_INVALID otherwise): shader-clock cycles summed over
+ * all waves of the last frame's tile kernel, per phase (set-up, pull/cull, vertex stage, classification, span raster,
+ * completion/rescan, end-of-chunk wait, fragment stage); n <= 16 */
+int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n);
 
 /* ---- grid_generate ----------------------------------------------------------------------- */
 /* make_grid (src/terrain/mesh.rs:35-90) computed on the GPU; outputs as the PyO3 wrapper returns

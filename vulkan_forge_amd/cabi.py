@@ -20,7 +20,7 @@ SYMBOLS = [
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
-    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_tile_stats", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
+    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_tile_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
     "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
@@ -62,6 +62,7 @@ _PROTOS = {
     "vf_terrain_enable_timing": (_i, [_vp, _i]),
     "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
     "vf_terrain_debug_tile_stats": (_i, [_vp, _vp, _u32]),
+    "vf_terrain_debug_phase_cycles": (_i, [_vp, _vp, _u32]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
     "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
@@ -170,6 +171,12 @@ class Terrain:
         n = self.timings()["tiles"]
         out = np.zeros((n, 3), np.uint32)
         self._check(self.lib.vf_terrain_debug_tile_stats(self.t, out.ctypes.data, n))
+        return out
+
+    def phase_cycles(self):
+        """(16,) u64: [0:8] shader-clock cycles per phase summed over waves, [8:16] event counts (libraries built with -DVF_PHASE_PROF only)."""
+        out = np.zeros(16, np.uint64)
+        self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 16))
         return out
 
     def timings(self):

@@ -268,7 +268,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_work_count, 2 * sizeof(uint32_t));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
-    A((void **)&t->d_stats, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t));
+    A((void **)&t->d_stats, (6 + 3 * (size_t)t->ntx * t->nty + 2 * kPhaseSlots) * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
@@ -422,7 +422,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t ntiles = t->ntx * local_tile_rows;
     hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
     if (t->timing) {
-        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 3 * (size_t)t->ntx * t->nty) * sizeof(uint32_t), s));
+        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (6 + 3 * (size_t)t->ntx * t->nty + 2 * kPhaseSlots) * sizeof(uint32_t), s));
         VF_HIP_TRY(hipEventRecord(ev[0], s));
     }
     const size_t rc_n = (size_t)t->nb * t->ntx;
@@ -508,6 +508,22 @@ int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles
     if (n > max_tiles) n = max_tiles;
     VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VF_OK;
+}
+
+int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n)
+{
+    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+#ifndef VF_PHASE_PROF
+    (void)n;
+    return fail(VF_ERR_INVALID, "library built without -DVF_PHASE_PROF");
+#else
+    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    if (n > kPhaseSlots) n = kPhaseSlots;
+    VF_HIP_TRY(hipMemcpy(dst, t->d_stats + ((4 + 3 * (size_t)t->ntx * t->nty + 1) & ~(size_t)1), n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VF_OK;
+#endif
 }
 
 int vf_terrain_enable_timing(vf_terrain *t, int enable)

@@ -206,9 +206,18 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // Lines whose candidate pixels are all final (owned by a higher block row) are skipped unsolved, and
 // only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
+#ifdef VF_PHASE_PROF
+struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips; };
+#define VF_RC_ARG , RasterCounts &RC
+#define VF_RC(...) __VA_ARGS__
+#else
+#define VF_RC_ARG
+#define VF_RC(...)
+#endif
 __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
-                                            int32_t X2, int32_t Y2, int32_t sub, int32_t nsub)
+                                            int32_t X2, int32_t Y2, int32_t sub, int32_t nsub VF_RC_ARG)
 {
+    VF_RC(RC.tris++;)
     const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
     const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
     const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
@@ -242,6 +251,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
     for (int32_t o = sub; o <= n_outer; o += nsub) {
         const uint64_t done = load_mask(fin, o_base + o);
         const uint64_t open = ~done & seg;
+        VF_RC(RC.lines++;)
         if (open == 0ull) continue;
         // ---- stage 1: conservative span from FP32 crossing estimates (exact alpha, relative error ~2^-22 => |error| < 1/4
         //      inside the clamp range): true lo is one of k, k+1, k+2; true hi one of k+1, k, k-1, k-2 ----
@@ -259,6 +269,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         if (lo_a > hi_a) continue;
         if ((bit_range(i_base + lo_a, i_base + hi_a) & open) == 0ull) continue;   // nothing this line could still change
         // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
+        VF_RC(RC.solved++;)
         int32_t lo = 0, hi = n_inner;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -275,6 +286,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         if (lo > hi) continue;
         uint64_t bits = bit_range(i_base + lo, i_base + hi) & ~done;
         const int32_t ol = o_base + o;
+        VF_RC(RC.painted += (uint32_t)__popcll(bits); RC.paint_lines += bits ? 1u : 0u;)
         while (bits) {
             const int32_t k = __builtin_ctzll(bits);
             bits &= bits - 1;
@@ -617,6 +629,13 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 //      publishes the final-pixel masks that later blocks, lines and pixels are culled against (stale masks are merely
 //      conservative); a fully final tile stops early;
 //   5. fragment stage on the LDS tile.
+#ifdef VF_PHASE_PROF   // diagnostics build: per-phase shader-clock cycles and event counts (vf_terrain_debug_phase_cycles)
+#define VF_PH_INIT uint64_t ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();
+#define VF_PH(p) { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[p] += ph_now - ph_last; ph_last = ph_now; }
+#else
+#define VF_PH_INIT
+#define VF_PH(p)
+#endif
 template <bool WRITE_VIS>
 __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ hblk,
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
@@ -655,6 +674,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
+    VF_PH_INIT
+    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[blockIdx.x].x;
     const uint32_t tile = work_tile(item);
@@ -773,6 +794,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         }
         __syncthreads();
         const uint32_t nlist = s_nlist;
+        VF_PH(0)
 
         // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
         uint32_t my_blocks = 0;
@@ -794,6 +816,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                 const uint64_t open = in ? (~load_mask(s_colfin, (int32_t)lane) & bit_range(y0, y1)) : 0ull;
                 live = __ballot(open != 0ull) != 0ull;
             }
+            VF_PH(1)
             if (live) {
                 ++my_blocks;
                 const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
@@ -813,6 +836,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
                 }
                 __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler from reordering
+                VF_PH(2)
                 // ---- pass A: lane = cell: classify both triangles, compact the survivors (ballot + prefix popcount) ----
                 uint32_t nsurv = 0;
                 {
@@ -841,12 +865,15 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     nsurv = n0 + (uint32_t)__popcll(m1);
                 }
                 __builtin_amdgcn_wave_barrier();
+                VF_RC(if (lane == 0) { rc_nsurv += nsurv; rc_live++; rc_empty += nsurv ? 0u : 1u; })
+                VF_PH(3)
                 // ---- pass B: the survivors share the wave: with few of them, 2..64 lanes split the lines of one triangle ----
                 {
                     uint32_t per = 1;                                   // lanes per survivor: largest power of two <= 64 / nsurv
                     while (per < 64u && per * 2u * nsurv <= 64u) per *= 2u;
                     const uint32_t shift = (uint32_t)__builtin_ctz(per);
                     for (uint32_t sbase = 0; sbase < nsurv; sbase += 64u >> shift) {
+                        VF_RC(if (lane == 0) rc_iters++;)
                         const uint32_t sidx = sbase + (lane >> shift);
                         if (sidx < nsurv) {
                             const uint32_t code = sS[wave][sidx];
@@ -856,22 +883,23 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
                             raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2],
-                                        (int32_t)(lane & (per - 1u)), (int32_t)per);
+                                        (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
                         }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                VF_PH(4)
             }
             // ---- completion: the DS queue of a wave is FIFO, so this decrement is ordered after the block's paints ----
             uint32_t old = 0;
             if (lane == 0) old = atomicSub(&s_pending[stepidx], 1u);
             old = __shfl(old, 0);
-            if (old != 1u) continue;
+            if (old != 1u) { VF_PH(5) continue; }
             // the step is complete: try to advance the frontier (first step that still has unfinished blocks)
             uint32_t got = 0;
             if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
             got = __shfl(got, 0);
-            if (!got) continue;                                        // somebody else is publishing; masks may lag, never lie
+            if (!got) { VF_PH(5) continue; }                           // somebody else is publishing; masks may lag, never lie
             uint32_t fr = *v_frontier;
             while (fr < nsteps && v_pending[fr] == 0u) ++fr;
             const uint32_t pub = *v_published;
@@ -881,7 +909,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) s_done = 1u; }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
+            VF_PH(5)
         }
+        VF_PH(1)
         if (lane == 0 && my_blocks) atomicAdd(&s_blocks, my_blocks);
         __syncthreads();
         if (s_done) break;                                             // uniform
@@ -896,9 +926,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         uint32_t all = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) all += s_part[w];
+        VF_PH(6)
         if (all >= tile_pixels) break;                                 // uniform: the whole tile is final
     }
     __syncthreads();
+    VF_PH(6)
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
         atomicAdd(&stats[4 + 3 * tile], s_blocks);
@@ -916,6 +948,19 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
+#ifdef VF_PHASE_PROF
+    VF_PH(7)
+    if (stats) {
+        unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + ((4 + 3 * (size_t)P.ntx * P.nty + 1) & ~(size_t)1));
+        if (lane == 0) {
+            for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
+            atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
+            atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
+        }
+        atomicAdd(&ph[11], (unsigned long long)RC.lines); atomicAdd(&ph[12], (unsigned long long)RC.solved);
+        atomicAdd(&ph[13], (unsigned long long)RC.painted); atomicAdd(&ph[14], (unsigned long long)RC.paint_lines);
+    }
+#endif
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
