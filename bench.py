@@ -4,11 +4,13 @@
   metric   Mpix/s terrain shade: W*H*frames / wall time, RGBA8 complete in HBM (rank 0 holds the gathered frame)
   workload C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
            (np.random.default_rng(20250816).random(float32)*0.5-0.25), default camera eye (3,2,3), viridis.
-           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort + k_tile (+ the band gather to rank 0 when N > 1).
-  N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): the frame is split into 64-row screen
-           bands, band b belongs to rank b % N; every rank renders only its bands, then rank 0 receives each
-           remote band directly into its place in the final image (point-to-point over xGMI).  Total work is
-           fixed, so scaling is "strong".
+           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort + k_tile (+ gather to rank 0 + stitch when N > 1).
+  N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): screen-tile split -- 64x64 tile (tx, ty)
+           belongs to rank (tx + skew*ty) % N; every rank renders only its tiles into a tile-major slab, the slabs go to
+           rank 0 point-to-point over xGMI (vulkan_forge_amd/dist.py::TileExchange) and vf_stitch_tiles_device writes the
+           frame.  The exchange is double-buffered: frame k travels while frame k+1 renders; every one of the K timed
+           frames is rendered, gathered and stitched inside the timed region (--serial: no overlap).  Total work is fixed,
+           so scaling is "strong".
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -27,7 +29,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BAND_H = 64
 
 
 def parse():
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fill camera) measurement")
     ap.add_argument("--check", action="store_true", help="after timing, compare the gathered frame with a single-rank render")
+    ap.add_argument("--serial", action="store_true", help="N>1: finish each frame's exchange before rendering the next (no overlap)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
                          "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
@@ -104,27 +106,60 @@ def main():
 
     t = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)
     t.set_height_device(d_height.data_ptr(), G, G)
-    t.set_shard(rank, world, BAND_H)
-    rows = t.local_rows()
-    assert rows == vdist.local_rows(H, rank, world, BAND_H)
-    local = torch.empty((rows, W, 4), dtype=torch.uint8, device=dev)
-    image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    t.set_output_device(image.data_ptr() if (world == 1) else local.data_ptr())   # N=1: render straight into the frame
-
     stream = torch.cuda.current_stream().cuda_stream
+    image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    depth = 1 if args.serial else 2
+    if world == 1:
+        t.set_output_device(image.data_ptr())                    # N=1: render straight into the frame
+        share = 1.0
+        ex = None
+    else:
+        # rehearsal: same exchange code over gloo through host memory (the device slabs are copied out and back in)
+        ex = vdist.TileExchange(W, H, "cpu" if args.rehearse else dev, depth=depth)
+        t.set_tile_shard(rank, world, ex.skew)
+        assert t.local_tiles() == len(vdist.tile_layout(W, H, rank, world, ex.skew))
+        share = t.local_tiles() / float(((W + 63) // 64) * ((H + 63) // 64))
+        if args.rehearse:
+            dev_local = torch.zeros(ex.stride * vdist.TILE_WORDS, dtype=torch.int32, device=dev)
+            dev_gathered = torch.zeros((world, ex.stride * vdist.TILE_WORDS), dtype=torch.int32, device=dev) if rank == 0 else None
+    frame_no = [0]
 
-    host_local = torch.empty((rows, W, 4), dtype=torch.uint8).pin_memory() if (args.rehearse and world > 1) else None
-    host_image = torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() if (args.rehearse and world > 1 and rank == 0) else None
+    def finish(slot):
+        """complete the exchange that last used `slot`; rank 0 writes that frame"""
+        g = ex.finish(slot)
+        if rank == 0 and g is not None and ex.pending_frame[slot]:
+            if args.rehearse:
+                dev_gathered.copy_(g)
+                g = dev_gathered
+            t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, stream)
+        if ex is not None:
+            ex.pending_frame[slot] = False
 
     def step():
+        if world == 1:
+            t.render(stream)
+            return
+        slot = frame_no[0] % depth
+        frame_no[0] += 1
+        finish(slot)                                                 # frame k - depth: its slab buffers are about to be reused
+        out = dev_local if args.rehearse else ex.output(slot)
+        t.set_output_device(out.data_ptr())
         t.render(stream)
-        if world > 1 and not args.rehearse:
-            vdist.gather_bands(local, image, H, BAND_H, dst=0)           # RCCL point-to-point, device memory
-        elif world > 1:
-            host_local.copy_(local, non_blocking=False)                  # rehearsal: same exchange over gloo via host memory
-            vdist.gather_bands(host_local, host_image, H, BAND_H, dst=0)
-            if rank == 0:
-                image.copy_(host_image, non_blocking=False)
+        if args.rehearse:
+            torch.cuda.synchronize()
+            ex.output(slot).copy_(out)
+        ex.start(slot)
+        ex.pending_frame[slot] = True
+        if args.serial:
+            finish(slot)
+
+    def flush():
+        if world > 1:
+            for k in range(depth):
+                finish((frame_no[0] + k) % depth)                    # oldest first
+
+    if ex is not None:
+        ex.pending_frame = [False] * depth
 
     SETTLE = 6   # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
                  # splitting) and needs a few frames of a new camera to converge; results never depend on it
@@ -135,6 +170,7 @@ def main():
             t.render(stream)
         for _ in range(warmup):
             step()
+        flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -142,6 +178,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        flush()                                                      # every timed frame is gathered and stitched in here
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -169,27 +206,29 @@ def main():
     if args.check:
         t.set_uniforms(camera_uniforms(args.camera, W, H))
         step()
+        flush()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         if rank == 0:
             got = image.clone()
-            t.set_shard(0, 1, BAND_H)
-            t.set_output_device(image.data_ptr())
-            t.render(stream)
+            single = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)   # unsharded handle, same inputs
+            single.set_height_device(d_height.data_ptr(), G, G)
+            single.set_uniforms(camera_uniforms(args.camera, W, H))
+            single.set_output_device(image.data_ptr())
+            single.render(stream)
             torch.cuda.synchronize()
             check = bool(torch.equal(got, image))
-            t.set_shard(rank, world, BAND_H)
-            t.set_output_device(image.data_ptr() if world == 1 else local.data_ptr())
+            single.close()
         if world > 1:
             dist.barrier()
 
     # ---- roofline of the dominant kernel (k_tile: vertex + setup + raster + fragment, fused) -------------------
     # algorithmic bytes per launch (whole frame): height texture read once + RGBA8 written once + LUT
     algo_bytes = 4 * G * G + 4 * W * H + 1024
-    share = rows / H                                              # this rank's share of the frame
-    kernel_s = tm["tile_ms"] * 1e-3
-    achieved = (4 * G * G + 4 * W * rows + 1024) / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    kernel_s = tm["tile_ms"] * 1e-3                               # `share` = this rank's share of the frame's pixels
+    rank_bytes = int(4 * G * G + 4 * W * H * share + 1024)
+    achieved = rank_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
@@ -202,7 +241,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(4 * G * G + 4 * W * rows + 1024), "kernel_ms": tm["tile_ms"],
+                "algorithmic_bytes_per_launch": rank_bytes, "kernel_ms": tm["tile_ms"],
                 "other_kernels_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
 
     # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
@@ -226,7 +265,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis",
                        "width": W, "height": H, "grid": G, "camera": args.camera,
-                       "parallelism": f"screen bands of {BAND_H} rows, round-robin over {world} GPU(s)" + (", p2p gather to rank 0 (RCCL)" if world > 1 else "")},
+                       "parallelism": "1 GPU, whole frame" if world == 1 else
+                                      f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), p2p gather to rank 0 (RCCL) "
+                                      f"+ stitch, {'serial' if args.serial else 'double-buffered'}"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_camera": extra,

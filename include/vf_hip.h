@@ -105,7 +105,20 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
 int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h);
 int vf_terrain_local_rows(const vf_terrain *t, uint32_t *rows);
 
-/* Render into a caller-provided device buffer of local_rows*W*4 bytes (NULL = internal buffer). */
+/* Multi-GPU screen split by interleaved 64 x 64 tiles ("screen-tile split", BASELINE.json configs[3]; new, the reference
+ * is single-device): tile (tx, ty) belongs to rank (tx + skew * ty) % nranks, so the heavy tiles of a frame -- they
+ * cluster along the terrain's silhouette -- spread over all ranks.  A rank stores its tiles densely, row-major by
+ * (ty, tx), each as 64 x 64 RGBA8 words (edge tiles keep the full slot): local tile k starts at byte k * 16384.
+ * vf_tile_layout lists a rank's tiles (tx | ty << 16; pure host arithmetic, no device needed; tiles may be NULL to
+ * count).  A tile-sharded handle is read with vf_terrain_read_tiles; rows come back after vf_stitch_tiles_device. */
+int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t skew);
+int vf_terrain_local_tiles(const vf_terrain *t, uint32_t *tiles);
+int vf_terrain_read_tiles(vf_terrain *t, uint8_t *dst, uint32_t first, uint32_t count);
+int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, uint32_t skew, uint32_t *tiles,
+                   uint32_t capacity, uint32_t *count);
+
+/* Render into a caller-provided device buffer of local_rows*W*4 bytes (tile shards: local_tiles*16384 bytes);
+ * NULL = internal buffer. */
 int vf_terrain_set_output_device(vf_terrain *t, void *dev_rgba);
 int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba);
 
@@ -126,9 +139,10 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
-/* diagnostics (timing enabled): per launched tile of the last frame, 3 words: candidate blocks processed,
- * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock) */
-int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles);
+/* diagnostics (timing enabled): per work item of the last frame (a busy tile, or one column strip of a heavy tile), in
+ * launch order, 4 words: item code (local tile | strip << 20 | log2(strips) << 24), candidate blocks processed,
+ * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock).  *count = items written. */
+int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items, uint32_t *count);
 /* diagnostics, only in libraries built with -DVF_PHASE_PROF (VF_ERR_INVALID otherwise): shader-clock cycles summed over
  * all waves of the last frame's tile kernel, per phase (set-up, pull/cull, vertex stage, classification, span raster,
  * completion/rescan, end-of-chunk wait, fragment stage); n <= 16 */
@@ -177,6 +191,9 @@ int vf_dem_read_patch(vf_dem *d, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
  * possible).  All pointers are device pointers. */
 int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width,
                            uint32_t height, uint32_t nranks, uint32_t band_h, void *stream);
+/* Same for tile shards: gather buffer [nranks][stride_tiles][64][64][4] (stride_tiles >= the largest shard) -> (H,W,4). */
+int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width, uint32_t height,
+                           uint32_t nranks, uint32_t skew, uint32_t stride_tiles, void *stream);
 
 #ifdef __cplusplus
 }

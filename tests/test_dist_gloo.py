@@ -64,3 +64,90 @@ def test_band_layout_properties():
         assert all(lay[k][1] + lay[k][2] == lay[k + 1][1] for k in range(len(lay) - 1))
         assert sum(vdist.local_rows(H, r, n, b) for r in range(n)) == H
     assert vdist.local_rows(4096, 3, 8, 64) == 512
+
+
+# ---- interleaved tiles (the bench's N > 1 layout) -------------------------------------------------------------
+def _tile_worker(rank, world, port, W, H, G, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from vulkan_forge_amd import dist as vdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = np.load(os.path.join(ROOT, "tests", "golden", "colormaps_rgba8.npz"))["viridis"]
+    u = O.default_uniforms(O.KIND_SCENE, W, H)
+    h = np.random.default_rng(5).random((24, 24), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+    full, _ = O.render_terrain(u, W, H, G, h, lut)                      # the pixels come from the oracle (no GPU in this tier)
+    ex = vdist.TileExchange(W, H, "cpu", depth=2)
+    lay = vdist.tile_layout(W, H, rank, world, ex.skew)
+    pad = np.zeros((((H + 63) // 64) * 64, ((W + 63) // 64) * 64, 4), np.uint8)
+    ok = True
+    nframes = 5
+    done = []
+
+    def finish(slot, frame):
+        g = ex.finish(slot)
+        if rank == 0 and frame >= 0:
+            img = np.zeros_like(pad)
+            for r in range(world):
+                slab = g[r].numpy().view(np.uint8).reshape(-1, 64, 64, 4)
+                for k, (tx, ty) in enumerate(vdist.tile_layout(W, H, r, world, ex.skew)):
+                    img[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = slab[k]
+            done.append(bool(np.array_equal(img[:H, :W], full ^ np.uint8(frame))))
+
+    in_slot = [-1, -1]
+    for f in range(nframes):                                            # frame f = the oracle frame xor f: slots must not mix frames
+        slot = f % 2
+        finish(slot, in_slot[slot])
+        pad[:H, :W] = full ^ np.uint8(f)
+        slab = np.zeros((ex.stride, 64, 64, 4), np.uint8)
+        for k, (tx, ty) in enumerate(lay):
+            slab[k] = pad[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64]
+        ex.output(slot).copy_(torch.from_numpy(slab.reshape(-1).view(np.int32)))
+        ex.start(slot)
+        in_slot[slot] = f
+    for k in range(2):
+        slot = (nframes + k) % 2
+        finish(slot, in_slot[slot])
+    dist.barrier()
+    if rank == 0:
+        q.put(len(done) == nframes and all(done))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 160, 256), (3, 200, 150)])
+def test_tile_shards_double_buffered_exchange(world, W, H):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, W, H, 32, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_tile_layout_properties():
+    from vulkan_forge_amd import dist as vdist
+    for W, H, n in ((4096, 4096, 8), (4096, 4096, 4), (1920, 1080, 8), (200, 150, 3), (64, 64, 2), (100, 100, 1), (130, 70, 6)):
+        skew = vdist.default_skew(n)
+        ntx, nty = (W + 63) // 64, (H + 63) // 64
+        seen = np.full((nty, ntx), -1)
+        sizes = []
+        for r in range(n):
+            lay = vdist.tile_layout(W, H, r, n, skew)
+            sizes.append(len(lay))
+            for tx, ty in lay:
+                assert seen[ty, tx] == -1 and (tx + skew * ty) % n == r
+                seen[ty, tx] = r
+            assert [tuple(x) for x in lay] == sorted((tuple(x) for x in lay), key=lambda p: (p[1], p[0]))   # row-major storage order
+        assert (seen >= 0).all()
+        assert vdist.stride_tiles(W, H, n, skew) == max(sizes)
+        if ntx >= n:
+            assert max(sizes) - min(sizes) <= nty                 # balanced to within one tile per tile row
+    assert vdist.default_skew(8) == 3 and vdist.default_skew(3) == 5 and vdist.default_skew(2) == 1
+    assert len(vdist.tile_layout(4096, 4096, 3, 8, 3)) == 512

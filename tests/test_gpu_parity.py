@@ -175,6 +175,19 @@ def test_c4_full_size_properties(c4, oracle, cam):
             assert loc.shape[0] == rows.size
             out[rows] = loc
         assert np.array_equal(out, a), (nranks, band)
+    # interleaved-tile shards (the bench's N > 1 layout): every rank's tile-major slab, placed by vf_tile_layout
+    from vulkan_forge_amd import cabi as _cabi
+    for nranks, skew in ((2, 1), (8, 3), (3, 5)):
+        out = np.zeros_like(a)
+        for r in range(nranks):
+            t.set_tile_shard(r, nranks, skew)
+            t.render()
+            tiles = t.read_tiles()
+            lay = _cabi.tile_layout(W, H, r, nranks, skew, lib=t.lib)
+            assert tiles.shape[0] == len(lay) == t.local_tiles()
+            for k, (tx, ty) in enumerate(lay):
+                out[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = tiles[k]
+        assert np.array_equal(out, a), (nranks, skew)
     t.set_shard(0, 1, 64)
 
 
@@ -255,6 +268,29 @@ torch.cuda.synchronize()
 ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
 assert np.array_equal(image.cpu().numpy(), ref)
 t.close()
+# tile shards on a frame whose edges cut tiles (200 x 150): slabs rendered into a caller-owned gather buffer + stitch kernel
+W, H, G = 200, 150, 48
+u = oracle.default_uniforms(1, W, H)
+ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
+for nr, skew in ((3, 5), (2, 1), (5, 3)):
+    t = cabi.Terrain(W, H, G, lut)
+    t.set_uniforms(u); t.set_height_device(d_h.data_ptr(), 64, 64)
+    stride = max(len(cabi.tile_layout(W, H, r, nr, skew, lib=t.lib)) for r in range(nr)) + 1     # a stride larger than needed is fine
+    gathered = torch.zeros((nr, stride * 4096), dtype=torch.int32, device="cuda")
+    for r in range(nr):
+        t.set_tile_shard(r, nr, skew)
+        t.set_output_device(gathered[r].data_ptr())
+        t.render(stream)
+    image = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    t.stitch_tiles(gathered.data_ptr(), image.data_ptr(), nr, skew, stride, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy(), ref), (nr, skew)
+    try:
+        t.read_rgba()
+        raise SystemExit("read_rgba must refuse a tile-sharded handle")
+    except cabi.VfError:
+        pass
+    t.close()
 print("INTEROP_OK")
 """
 

@@ -11,12 +11,13 @@ h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float3
 t = cabi.Terrain(W, H, G, lut, lib=cabi.load(sys.argv[1])); t.set_height(h); print(sys.argv[1])
 for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
-    for band in (64,):
+    for band in (64, 0):                                  # 0 = interleaved tiles
         for n in (1, 2, 4, 8):
             times = []
             for r in range(n):
-                t.set_shard(r, n, band)
-                for _ in range(3): t.render()
+                if band: t.set_shard(r, n, band)
+                else: t.set_tile_shard(r, n, {1: 1, 2: 1, 4: 3, 8: 3}[n])
+                for _ in range(6): t.render()
                 t.enable_timing(True); t.render(); t.render(); tm = t.timings(); t.enable_timing(False)
                 times.append(tm["total_ms"])
             print(f"{cam:8s} band={band:4d} N={n}: per-rank ms max={max(times):.3f} min={min(times):.3f} sum={sum(times):.3f}  -> speedup vs N=1 (compute only) = {base/max(times) if n>1 else 1.0:.2f}" if n > 1 else f"{cam:8s} band={band:4d} N=1: {times[0]:.3f} ms", flush=True)

@@ -1,3 +1,4 @@
+"""Heaviest work items of the C4 frame: which tiles / strips set the critical path of k_tile."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,13 +9,19 @@ W = H = G = 4096
 lut = np.load("tests/golden/colormaps_rgba8.npz")["viridis"]
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, lut); t.set_height(h)
-t.set_uniforms(b.camera_uniforms("default", W, H))
-for (r, n) in ((0, 1), (2, 8), (3, 8)):
-    t.set_shard(r, n, 64)
-    for _ in range(3): t.render()
-    t.enable_timing(True); t.render(); tm = t.timings(); ts = t.tile_stats(); t.enable_timing(False)
-    order = np.argsort(-ts[:, 1].astype(np.int64))[:8]
-    ntx = W // 64
-    print(f"rank {r}/{n}: total {tm['total_ms']:.3f} ms tile {tm['tile_ms']:.3f} plan {tm['plan_ms']:.3f} boxes {tm['ranges_ms']:.3f}; busy tiles {(ts[:,0]>0).sum()} blocks {ts[:,0].sum()}")
-    for k in order:
-        print(f"    tile {k} (tx={k % ntx}, local ty={k // ntx}) blocks={ts[k,0]} raster_ms={ts[k,1]*1e-5:.3f} total_ms={ts[k,2]*1e-5:.3f}")
+for cam in ("default", "fill"):
+    t.set_uniforms(b.camera_uniforms(cam, W, H))
+    for (r, n) in ((0, 1), (2, 8)):
+        if n == 1: t.set_shard(0, 1, 64)
+        else: t.set_tile_shard(r, n, 3)
+        lay = cabi.tile_layout(W, H, r, n, 3, lib=t.lib) if n > 1 else None
+        for _ in range(6): t.render()
+        t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
+        ms = it[:, 2] * 1e-5
+        order = np.argsort(-ms)[:12]
+        print(f"{cam} rank {r}/{n}: total {tm['total_ms']:.3f} ms tile {tm['tile_ms']:.3f}; items {len(it)} (strips: {np.bincount(it[:,0] >> 24, minlength=5).tolist()} by log2) "
+              f"pairs {it[:,1].sum()} sum item-ms {ms.sum():.1f} (/256 = {ms.sum()/256:.3f}) max {ms.max():.3f} p50 {np.median(ms):.3f}")
+        for k in order:
+            code = int(it[k, 0]); tile = code & 0xFFFFF; part = (code >> 20) & 15; lg = code >> 24
+            tx, ty = (tile % 64, tile // 64) if lay is None else lay[tile]
+            print(f"    item {k:5d}: tile ({tx},{ty}) strip {part}/{1 << lg} blocks={it[k,1]} raster_ms={ms[k]:.3f} frag_ms={(int(it[k,3])-int(it[k,2]))*1e-5:.3f} us/block={1e3*ms[k]/max(it[k,1],1):.2f}")

@@ -18,10 +18,11 @@ VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -
 SYMBOLS = [
     "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
-    "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_output_device",
+    "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
+    "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
-    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_tile_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
-    "vf_stitch_bands_device",
+    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
+    "vf_stitch_bands_device", "vf_stitch_tiles_device",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
     "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
 ]
@@ -53,6 +54,10 @@ _PROTOS = {
     "vf_terrain_set_height_device": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_set_shard": (_i, [_vp, _u32, _u32, _u32]),
     "vf_terrain_local_rows": (_i, [_vp, C.POINTER(_u32)]),
+    "vf_terrain_set_tile_shard": (_i, [_vp, _u32, _u32, _u32]),
+    "vf_terrain_local_tiles": (_i, [_vp, C.POINTER(_u32)]),
+    "vf_terrain_read_tiles": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_tile_layout": (_i, [_u32, _u32, _u32, _u32, _u32, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_set_output_device": (_i, [_vp, _vp]),
     "vf_terrain_rgba_device": (_i, [_vp, C.POINTER(_vp)]),
     "vf_terrain_render": (_i, [_vp, _vp]),
@@ -61,12 +66,13 @@ _PROTOS = {
     "vf_terrain_read_visibility": (_i, [_vp, _vp]),
     "vf_terrain_enable_timing": (_i, [_vp, _i]),
     "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
-    "vf_terrain_debug_tile_stats": (_i, [_vp, _vp, _u32]),
+    "vf_terrain_debug_item_stats": (_i, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_phase_cycles": (_i, [_vp, _vp, _u32]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
     "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
     "vf_stitch_bands_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
+    "vf_stitch_tiles_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp]),
     "vf_dem_create": (_i, [_vp, C.POINTER(_vp)]),
     "vf_dem_destroy": (None, [_vp]),
     "vf_dem_set_heights_f32": (_i, [_vp, _vp, _u32, _u32, _f]),
@@ -91,6 +97,19 @@ def load(path: str = DEFAULT_LIB) -> C.CDLL:
 
 class VfError(RuntimeError):
     pass
+
+
+def tile_layout(width, height, rank, nranks, skew=3, lib=None):
+    """Tiles of `rank` in its storage order as an (n, 2) int array of (tx, ty) -- vf_tile_layout, host arithmetic only."""
+    lib = lib or load()
+    n = _u32()
+    if lib.vf_tile_layout(width, height, rank, nranks, skew, None, 0, C.byref(n)) != VF_OK:
+        raise VfError(lib.vf_last_error().decode())
+    packed = np.zeros(max(n.value, 1), np.uint32)
+    if lib.vf_tile_layout(width, height, rank, nranks, skew, packed.ctypes.data, n.value, C.byref(n)) != VF_OK:
+        raise VfError(lib.vf_last_error().decode())
+    packed = packed[:n.value]
+    return np.stack([packed & 0xFFFF, packed >> 16], axis=1).astype(np.int64)
 
 
 class Terrain:
@@ -138,6 +157,26 @@ class Terrain:
     def set_shard(self, rank, nranks, band_h=64):
         self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))
 
+    def set_tile_shard(self, rank, nranks, skew=3):
+        self._check(self.lib.vf_terrain_set_tile_shard(self.t, rank, nranks, skew))
+
+    def local_tiles(self):
+        n = _u32()
+        self._check(self.lib.vf_terrain_local_tiles(self.t, C.byref(n)))
+        return n.value
+
+    def read_tiles(self):
+        """(local_tiles, 64, 64, 4) uint8, the tile-major buffer of a tile-sharded handle."""
+        n = self.local_tiles()
+        out = np.empty((n, 64, 64, 4), np.uint8)
+        if n:
+            self._check(self.lib.vf_terrain_read_tiles(self.t, out.ctypes.data, 0, n))
+        return out
+
+    def stitch_tiles(self, gathered_dptr, image_dptr, nranks, skew, stride_tiles, stream=None):
+        self._check(self.lib.vf_stitch_tiles_device(self.ctx, _vp(gathered_dptr), _vp(image_dptr), self.W, self.H, nranks, skew,
+                                                    stride_tiles, _vp(stream or 0)))
+
     def local_rows(self):
         r = _u32()
         self._check(self.lib.vf_terrain_local_rows(self.t, C.byref(r)))
@@ -166,11 +205,23 @@ class Terrain:
     def enable_timing(self, on=True):
         self._check(self.lib.vf_terrain_enable_timing(self.t, int(on)))
 
+    def item_stats(self):
+        """(items, 4) u32 per work item of the last frame: code (local tile | strip << 20 | log2 strips << 24), candidate
+        blocks, raster ticks, raster+fragment ticks (10 ns)."""
+        cap = self.timings()["tiles"] + 2048
+        out = np.zeros((cap, 4), np.uint32)
+        n = _u32()
+        self._check(self.lib.vf_terrain_debug_item_stats(self.t, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value]
+
     def tile_stats(self):
-        """(ntiles, 3) u32: candidate blocks, raster ticks, raster+fragment ticks (10 ns) per launched tile."""
-        n = self.timings()["tiles"]
-        out = np.zeros((n, 3), np.uint32)
-        self._check(self.lib.vf_terrain_debug_tile_stats(self.t, out.ctypes.data, n))
+        """(ntiles, 3) u32 per local tile: candidate blocks (sum over strips), raster ticks, raster+fragment ticks (max)."""
+        it = self.item_stats()
+        out = np.zeros((self.timings()["tiles"], 3), np.uint32)
+        tile = it[:, 0] & 0xFFFFF
+        np.add.at(out[:, 0], tile, it[:, 1])
+        np.maximum.at(out[:, 1], tile, it[:, 2])
+        np.maximum.at(out[:, 2], tile, it[:, 3])
         return out
 
     def phase_cycles(self):

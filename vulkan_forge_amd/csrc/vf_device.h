@@ -48,6 +48,8 @@ struct FrameParams {
     uint32_t tw, th;
     uint32_t rank, nranks, band_shift, band_h;
     uint32_t local_rows;
+    uint32_t shard_tiles;           // 0: whole frame / row bands (local rows, row-major); 1: interleaved tiles (tile-major)
+    const uint32_t *tile_map;       // shard_tiles: local tile -> tx | ty << 16
     uint32_t clear_rgba;            // packed sRGB8 clear colour
 };
 

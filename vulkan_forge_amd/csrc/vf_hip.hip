@@ -78,7 +78,7 @@ struct vf_terrain {
     uint32_t nb = 0, nblocks = 0;        // 16x16-cell blocks per side / in total
     uint32_t ntx = 0, nty = 0;           // 64x64 screen tiles
     // shard
-    uint32_t rank = 0, nranks = 1, band_h = kTileH, local_rows = 0;
+    uint32_t rank = 0, nranks = 1, band_h = kTileH, local_rows = 0, skew = 0;
     // uniforms
     float u[44];
     bool have_uniforms = false;
@@ -101,6 +101,9 @@ struct vf_terrain {
     uint32_t *d_last_blocks = nullptr;   // feedback: blocks rasterised per tile in the previous frame (+ [ntiles] = mean)
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
+    uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
+    bool shard_tiles = false;
+    uint32_t local_tiles = 0;            // tiles this handle renders (= ntx * local tile rows unless tile-sharded)
     uint32_t *d_rgba = nullptr;
     uint32_t *d_vis = nullptr;           // only allocated for vf_terrain_read_visibility
     uint32_t *d_stats = nullptr;         // [0] (tile, block) pairs rasterised
@@ -240,6 +243,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     t->ntx = (width + kTileW - 1) / kTileW;
     t->nty = (height + kTileH - 1) / kTileH;
     t->local_rows = height;
+    t->local_tiles = t->ntx * t->nty;
     std::memset(t->u, 0, sizeof t->u);
 
     float lut[768];
@@ -267,8 +271,9 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_last_blocks, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
     A((void **)&t->d_work_count, 2 * sizeof(uint32_t));
     A((void **)&t->d_lut, sizeof lut);
-    A((void **)&t->d_rgba_own, (size_t)width * height * sizeof(uint32_t));
-    A((void **)&t->d_stats, (6 + 3 * (size_t)t->ntx * t->nty + 2 * kPhaseSlots) * sizeof(uint32_t));
+    A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
+    A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
+    A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
@@ -295,7 +300,7 @@ void vf_terrain_destroy(vf_terrain *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
-                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats };
+                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
@@ -357,10 +362,69 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     t->rank = rank; t->nranks = nranks; t->band_h = band_h;
+    t->shard_tiles = false;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
+    t->local_tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
     t->rendered = false;
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    return VF_OK;
+}
+
+int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, uint32_t skew, uint32_t *tiles, uint32_t capacity,
+                   uint32_t *count)
+{
+    if (!count) return fail(VF_ERR_INVALID, "NULL argument");
+    if (width == 0 || height == 0 || nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "empty frame or rank >= nranks");
+    const uint32_t ntx = (width + kTileW - 1) / kTileW, nty = (height + kTileH - 1) / kTileH;
+    if (ntx > 0xFFFFu || nty > 0xFFFFu) return fail(VF_ERR_INVALID, "frame too large");
+    uint32_t n = 0;
+    for (uint32_t ty = 0; ty < nty; ++ty)
+        for (uint32_t tx = 0; tx < ntx; ++tx)
+            if ((tx + skew * ty) % nranks == rank) {
+                if (tiles && n < capacity) tiles[n] = tx | (ty << 16);
+                ++n;
+            }
+    *count = n;
+    return VF_OK;
+}
+
+int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t skew)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    std::vector<uint32_t> map((size_t)t->ntx * t->nty);
+    uint32_t n = 0;
+    int rc = vf_tile_layout(t->W, t->H, rank, nranks, skew, map.data(), (uint32_t)map.size(), &n);
+    if (rc != VF_OK) return rc;
+    if (n) VF_HIP_TRY(hipMemcpy(t->d_tile_map, map.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    t->shard_tiles = true; t->local_tiles = n;
+    t->rank = rank; t->nranks = nranks; t->skew = skew;
+    t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
+    t->rendered = false;
+    VF_HIP_TRY(hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    return VF_OK;
+}
+
+int vf_terrain_local_tiles(const vf_terrain *t, uint32_t *tiles)
+{
+    if (!t || !tiles) return fail(VF_ERR_INVALID, "NULL argument");
+    *tiles = t->local_tiles;
+    return VF_OK;
+}
+
+int vf_terrain_read_tiles(vf_terrain *t, uint8_t *dst, uint32_t first, uint32_t count)
+{
+    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->shard_tiles) return fail(VF_ERR_INVALID, "handle is not tile-sharded");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    if ((uint64_t)first + count > t->local_tiles) return fail(VF_ERR_INVALID, "tile range outside the local tiles");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    const size_t tile_px = (size_t)kTileW * kTileH;
+    VF_HIP_TRY(hipMemcpy(dst, t->d_rgba + first * tile_px, count * tile_px * 4, hipMemcpyDeviceToHost));
     return VF_OK;
 }
 
@@ -404,6 +468,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
+    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map;
     const SrgbTables &T = tables();
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
 }
@@ -418,11 +483,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         VF_HIP_TRY(hipGetLastError());
         t->bounds_dirty = false;
     }
-    const uint32_t local_tile_rows = (t->local_rows + kTileH - 1) / kTileH;
-    const uint32_t ntiles = t->ntx * local_tile_rows;
+    const uint32_t ntiles = t->local_tiles;
     hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
     if (t->timing) {
-        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (6 + 3 * (size_t)t->ntx * t->nty + 2 * kPhaseSlots) * sizeof(uint32_t), s));
+        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t), s));
         VF_HIP_TRY(hipEventRecord(ev[0], s));
     }
     const size_t rc_n = (size_t)t->nb * t->ntx;
@@ -474,6 +538,7 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
 {
     if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
     if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    if (t->shard_tiles) return fail(VF_ERR_INVALID, "tile-sharded handle: read with vf_terrain_read_tiles");
     if ((uint64_t)y0 + rows > t->local_rows) return fail(VF_ERR_INVALID, "row range outside the local rows");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
@@ -485,6 +550,7 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
 {
     if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
     if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
+    if (t->shard_tiles) return fail(VF_ERR_INVALID, "visibility read-back needs a row-oriented handle (vf_terrain_set_shard)");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     // the visibility tile normally lives and dies in LDS: re-render the current frame with the debug store enabled
     const size_t npx = (size_t)t->W * t->H;
@@ -498,15 +564,17 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
     return VF_OK;
 }
 
-int vf_terrain_debug_tile_stats(vf_terrain *t, uint32_t *dst, uint32_t max_tiles)
+int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items, uint32_t *count)
 {
-    if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t || !dst || !count) return fail(VF_ERR_INVALID, "NULL argument");
     if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    uint32_t n = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
-    if (n > max_tiles) n = max_tiles;
-    VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 3 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    VF_HIP_TRY(hipMemcpy(&n, t->d_work_count, sizeof n, hipMemcpyDeviceToHost));
+    if (n > max_items) n = max_items;
+    if (n) VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *count = n;
     return VF_OK;
 }
 
@@ -521,7 +589,7 @@ int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n)
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
     if (n > kPhaseSlots) n = kPhaseSlots;
-    VF_HIP_TRY(hipMemcpy(dst, t->d_stats + ((4 + 3 * (size_t)t->ntx * t->nty + 1) & ~(size_t)1), n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget), n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VF_OK;
 #endif
 }
@@ -558,7 +626,7 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
     uint32_t c[4];
     VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));
     out->blocks_rasterised = c[0];
-    out->tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
+    out->tiles = t->local_tiles;
     return VF_OK;
 }
 
@@ -846,6 +914,28 @@ int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     size_t nvec = (size_t)height * row_vec4;
     hipLaunchKernelGGL(k_stitch_bands, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const uint4 *)dev_gathered,
                        (uint4 *)dev_image, row_vec4, height, nranks, ilog2(band_h), band_h, height / nranks);
+    VF_HIP_TRY(hipGetLastError());
+    return VF_OK;
+}
+
+int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width, uint32_t height,
+                           uint32_t nranks, uint32_t skew, uint32_t stride_tiles, void *stream)
+{
+    if (!ctx || !dev_gathered || !dev_image) return fail(VF_ERR_INVALID, "NULL argument");
+    if (width == 0 || height == 0 || nranks == 0) return fail(VF_ERR_INVALID, "empty frame or nranks == 0");
+    const uint32_t ntx = (width + kTileW - 1) / kTileW, nty = (height + kTileH - 1) / kTileH;
+    uint32_t most = 0;
+    for (uint32_t r = 0; r < nranks; ++r) {
+        uint32_t n = 0;
+        int rc = vf_tile_layout(width, height, r, nranks, skew, nullptr, 0, &n);
+        if (rc != VF_OK) return rc;
+        most = n > most ? n : most;
+    }
+    if (stride_tiles < most) return fail(VF_ERR_INVALID, "stride_tiles is smaller than the largest shard");
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(k_stitch_tiles, dim3(ntx * nty), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
+                       ntx, nranks, skew, stride_tiles);
     VF_HIP_TRY(hipGetLastError());
     return VF_OK;
 }

@@ -13,7 +13,7 @@
 //                     framebuffer-sized intermediate ever touches HBM.
 //   k_grid_*          grid_generate (bit-exact make_grid)
 //   k_triangle        the triangle smoke path
-//   k_stitch_bands    multi-GPU de-interleave
+//   k_stitch_bands / k_stitch_tiles   multi-GPU de-interleave
 //
 // Painter's order: the reference pipeline has no depth buffer (src/terrain/pipeline.rs:133), so the
 // visible fragment is the LAST covering front-facing primitive in index order == max primitive id.
@@ -495,13 +495,29 @@ __device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin
 // appended to a work list with a weight (number of block rows in reach) and k_plan_sort orders the list
 // heaviest first, so the long-running tiles of the frame start first and the tail of the launch stays short.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_rect(const FrameParams &P, uint32_t tile, int32_t &px_lo, int32_t &px_hi, int32_t &py_lo, int32_t &py_hi,
-                                          uint32_t &lty)
+// local tile -> pixel rectangle, tile column, and where its pixels go: pixel (lx, ly) of the tile is stored at
+// out_base + ly * out_stride + lx.  Band shards keep their rows densely packed (row-major, stride W); tile shards keep
+// their tiles densely packed (tile-major, 64 x 64 words each), which is what the multi-GPU exchange moves as one slab.
+struct TilePlace { uint32_t tx; size_t out_base; uint32_t out_stride; };
+__device__ __forceinline__ TilePlace tile_rect(const FrameParams &P, uint32_t tile, int32_t &px_lo, int32_t &px_hi, int32_t &py_lo, int32_t &py_hi)
 {
-    const uint32_t ttx = tile % P.ntx;
-    lty = tile / P.ntx;
-    px_lo = (int32_t)(ttx * kTileW); px_hi = min(px_lo + kTileW, (int32_t)P.W) - 1;
-    py_lo = (int32_t)global_row(P, lty * kTileH); py_hi = min(py_lo + kTileH, (int32_t)P.H) - 1;   // band_h is a multiple of kTileH
+    TilePlace tp;
+    if (P.shard_tiles) {
+        const uint32_t m = P.tile_map[tile];
+        tp.tx = m & 0xFFFFu;
+        py_lo = (int32_t)((m >> 16) * kTileH);
+        tp.out_base = (size_t)tile * (kTileW * kTileH);
+        tp.out_stride = kTileW;
+    } else {
+        tp.tx = tile % P.ntx;
+        const uint32_t lty = tile / P.ntx;
+        py_lo = (int32_t)global_row(P, lty * kTileH);                  // band_h is a multiple of kTileH
+        tp.out_base = (size_t)lty * kTileH * P.W + (size_t)tp.tx * kTileW;
+        tp.out_stride = P.W;
+    }
+    px_lo = (int32_t)(tp.tx * kTileW); px_hi = min(px_lo + kTileW, (int32_t)P.W) - 1;
+    py_hi = min(py_lo + kTileH, (int32_t)P.H) - 1;
+    return tp;
 }
 
 // work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2, 4, 8 or 16 column strips, each its own
@@ -529,12 +545,11 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
 {
     __shared__ uint32_t s_hits;
     int32_t px_lo, px_hi, py_lo, py_hi;
-    uint32_t lty;
-    tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi, lty);
+    const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
     if (threadIdx.x == 0) s_hits = 0;
     __syncthreads();
     uint32_t hits = 0;
-    const uint32_t tcol = blockIdx.x % P.ntx;
+    const uint32_t tcol = tp.tx;
     for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
         const PixelBox rr = row_boxes[r];
         hits += (rc_lo[r * P.ntx + tcol] < rc_hi[r * P.ntx + tcol] && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     const int32_t w = px_hi - px_lo + 1, h = py_hi - py_lo + 1;
     for (int32_t k = threadIdx.x; k < w * h; k += 256) {
         const int32_t ly = k / w, lx = k - ly * w;
-        const size_t o = (size_t)(lty * kTileH + (uint32_t)ly) * P.W + (uint32_t)(px_lo + lx);
+        const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)lx;
         rgba[o] = P.clear_rgba;
         if (vis_out) vis_out[o] = 0u;
     }
@@ -679,11 +694,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[blockIdx.x].x;
     const uint32_t tile = work_tile(item);
-    uint32_t lty;
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
-    tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi, lty);
-    const uint32_t tcol = tile % P.ntx;
+    const TilePlace tp = tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi);
+    const uint32_t tcol = tp.tx;
+    const int32_t tile_x0 = T.px_lo;                       // the tile's left edge (T.px_lo becomes the strip's below)
     work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2..16 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
@@ -933,8 +948,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     VF_PH(6)
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
-        atomicAdd(&stats[4 + 3 * tile], s_blocks);
-        atomicMax(&stats[5 + 3 * tile], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start));   // raster phase, 10 ns ticks
+        stats[4 + 4 * blockIdx.x] = item; stats[5 + 4 * blockIdx.x] = s_blocks;
+        stats[6 + 4 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
@@ -944,14 +959,14 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
-        const size_t o = (size_t)(lty * kTileH + (uint32_t)ly) * P.W + (uint32_t)px;
+        const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
         rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
 #ifdef VF_PHASE_PROF
     VF_PH(7)
     if (stats) {
-        unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + ((4 + 3 * (size_t)P.ntx * P.nty + 1) & ~(size_t)1));
+        unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + 4 + 4 * ((size_t)P.ntx * P.nty + kSplitBudget));
         if (lane == 0) {
             for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
             atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
@@ -964,7 +979,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
-        if (stats) atomicMax(&stats[6 + 3 * tile], ticks);    // raster + fragment phase
+        if (stats) stats[7 + 4 * blockIdx.x] = ticks;        // raster + fragment phase
     }
 }
 
@@ -1107,6 +1122,32 @@ __global__ void k_stitch_bands(const uint4 *__restrict__ src, uint4 *__restrict_
     uint32_t b = y >> band_shift, r = b % nranks;
     uint32_t ly = ((b / nranks) << band_shift) + (y & (band_h - 1u));
     dst[p] = src[((size_t)r * local_rows + ly) * row_vec4 + xq];
+}
+
+// multi-GPU, tile shards: [nranks][stride_tiles][64][64] rank-major gather buffer -> (H, W) image.  Tile (tx, ty) belongs
+// to rank (tx + skew * ty) % nranks; a rank numbers its tiles row-major.  One workgroup per screen tile.
+__global__ __launch_bounds__(256) void k_stitch_tiles(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t W, uint32_t H,
+                                                      uint32_t ntx, uint32_t nranks, uint32_t skew, uint32_t stride_tiles)
+{
+    __shared__ uint32_t s_local;
+    const uint32_t tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const uint32_t r = (tx + skew * ty) % nranks;
+    if (threadIdx.x == 0) {
+        uint32_t before = 0;                               // tiles of rank r in the rows above
+        for (uint32_t t = 0; t < ty; ++t) {
+            const uint32_t first = (r + nranks - (skew * t) % nranks) % nranks;
+            before += first < ntx ? (ntx - 1u - first) / nranks + 1u : 0u;
+        }
+        const uint32_t first = (r + nranks - (skew * ty) % nranks) % nranks;
+        s_local = before + (tx - first) / nranks;
+    }
+    __syncthreads();
+    const uint32_t *tile = src + ((size_t)r * stride_tiles + s_local) * (kTileW * kTileH);
+    const uint32_t x0 = tx * kTileW, y0 = ty * kTileH;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)(kTileW * kTileH); k += 256) {
+        const uint32_t lx = k % kTileW, ly = k / kTileW;
+        if (x0 + lx < W && y0 + ly < H) dst[(size_t)(y0 + ly) * W + x0 + lx] = tile[k];
+    }
 }
 
 } // namespace vf

@@ -1,6 +1,16 @@
-"""Screen-space band sharding across the GPUs of one node (one process per GPU, torch.distributed).
+"""Screen-space sharding across the GPUs of one node (one process per GPU, torch.distributed).
 
-The reference is single-device; this is the multi-GPU layer SURVEY.md 8(e) asks for.  Pixel row y belongs
+Two shard shapes (both new: the reference is single-device):
+
+* interleaved 64 x 64 tiles (`TileExchange`, the bench's N > 1 path): tile (tx, ty) belongs to rank
+  (tx + skew * ty) % nranks, so the expensive tiles of a frame (they cluster along the terrain's silhouette) spread over
+  all ranks.  A rank keeps its tiles densely packed (tile-major); one exchange step moves each rank's slab to rank 0
+  (point-to-point, every sender on its own xGMI link, no ring), where `vf_stitch_tiles_device` writes the frame.  The
+  exchange is asynchronous and double-buffered: frame k travels while frame k+1 renders.
+* 64-row bands (`gather_bands`): band b belongs to rank b % nranks; bands are contiguous slabs of the final image, so
+  rank 0 receives them in place without a stitch pass.  Balanced only when the work is spread over the frame's height.
+
+Band sharding in detail: pixel row y belongs
 to rank ((y // band_h) % nranks); every rank renders only its bands (the tile kernel never launches a
 workgroup for a foreign tile, and blocks that cannot reach an owned tile are never rasterised), keeps them
 densely packed ("local rows", band order) and one exchange step moves them to rank 0: each band is a
@@ -60,3 +70,79 @@ def gather_bands(local, image, height: int, band_h: int, dst: int = 0, group=Non
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return ops
+
+
+# ---- interleaved tiles ------------------------------------------------------------------------------------------
+TILE = 64
+TILE_WORDS = TILE * TILE          # RGBA8 pixels (32-bit words) per tile slot
+
+
+def default_skew(nranks: int) -> int:
+    """Row-to-row shift of the tile -> rank map: the smallest odd s >= 3 coprime to nranks (1 for nranks <= 2)."""
+    from math import gcd
+    if nranks <= 2:
+        return 1
+    s = 3
+    while gcd(s, nranks) != 1:
+        s += 2
+    return s
+
+
+def tile_layout(width: int, height: int, rank: int, nranks: int, skew: int):
+    """(n, 2) array of (tx, ty): the tiles of `rank` in storage order (the library's vf_tile_layout; host arithmetic)."""
+    from . import cabi
+    return cabi.tile_layout(width, height, rank, nranks, skew)
+
+
+def stride_tiles(width: int, height: int, nranks: int, skew: int) -> int:
+    """Tile slots per rank in the gather buffer = the largest shard."""
+    return max(len(tile_layout(width, height, r, nranks, skew)) for r in range(nranks))
+
+
+class TileExchange:
+    """Double-buffered gather of tile shards to rank `dst`.
+
+    Every rank renders frame k into `output(k % depth)` (int32 tensor, stride*4096 words; on `dst` this is its own slot of
+    the gather buffer, so the root's tiles are never copied), calls `start(slot)` and goes on with the next frame;
+    `finish(slot)` -- called before the slot is rendered into again, and for every slot at the end -- makes the current
+    stream wait for that exchange and returns the gather buffer [nranks, stride*4096] on `dst` (None elsewhere) for the
+    caller to stitch.  Works on CUDA tensors with the nccl (RCCL) backend and on CPU tensors with gloo.
+    """
+
+    def __init__(self, width, height, device, depth=2, dst=0, skew=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group, self.dst = dist, group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.skew = default_skew(self.world) if skew is None else skew
+        self.stride = stride_tiles(width, height, self.world, self.skew)
+        self.depth = depth
+        words = self.stride * TILE_WORDS
+        if self.rank == dst:
+            self.gathered = [torch.zeros((self.world, words), dtype=torch.int32, device=device) for _ in range(depth)]
+            self.local = [g[dst] for g in self.gathered]
+        else:
+            self.gathered = [None] * depth
+            self.local = [torch.zeros(words, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.pending = [None] * depth
+
+    def output(self, slot):
+        return self.local[slot]
+
+    def start(self, slot):
+        if self.world == 1:
+            return
+        dist = self.dist
+        if self.rank == self.dst:
+            ops = [dist.P2POp(dist.irecv, self.gathered[slot][r], r, self.group) for r in range(self.world) if r != self.dst]
+        else:
+            ops = [dist.P2POp(dist.isend, self.local[slot], self.dst, self.group)]
+        self.pending[slot] = dist.batch_isend_irecv(ops)
+
+    def finish(self, slot):
+        if self.pending[slot] is not None:
+            for w in self.pending[slot]:
+                w.wait()
+            self.pending[slot] = None
+        return self.gathered[slot]
