@@ -134,6 +134,11 @@ int vf_terrain_sync(vf_terrain *t);
 /* copy_texture_to_buffer + map + un-pad (src/terrain/mod.rs:439-485): local rows [y0, y0+rows)
  * into dst (rows*W*4 bytes).  Synchronises the last render. */
 int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows);
+/* Read-back for render_png (src/terrain/mod.rs:439-490): the last frame as PNG scanlines -- per row one filter-type byte
+ * (row-adaptive: the filter with the smallest sum of absolute residuals, chosen on the GPU) followed by W*4 filtered
+ * bytes -- in pinned host memory owned by the handle (allocated once, not per call as the reference's read-back buffer
+ * :446-451), valid until the next call on the handle.  The host only deflates.  Whole-frame handles only. */
+int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines, size_t *nbytes);
 /* debug/parity: per-pixel visible primitive id + 1 (0 = background) of the last render, local rows */
 int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 

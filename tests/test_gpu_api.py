@@ -52,6 +52,38 @@ def test_png_holds_exactly_the_rendered_pixels(tmp_path, oracle, luts):
     assert np.abs(png.astype(int) - ref.astype(int)).max() <= 1
 
 
+def test_png_scanlines_are_filtered_on_the_gpu_like_the_host_encoder(tmp_path, luts):
+    """vf_terrain_read_png_scanlines = the host encoder's adaptive filter, row for row and byte for byte
+    (None/Sub/Up/Average/Paeth, smallest sum of absolute residuals, first on ties), so render_png only deflates."""
+    import zlib
+    from PIL import Image
+    from test_host_api import _png_scanlines
+    from vulkan_forge_amd import cabi
+    import oracle as O
+    for W, H, G in ((200, 120, 32), (1, 1, 2), (257, 65, 16), (1920, 1080, 256)):
+        t = cabi.Terrain(W, H, G, luts["terrain"])
+        try:
+            t.set_uniforms(O.default_uniforms(1, W, H))
+            t.set_height(np.random.default_rng(W).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25))
+            t.render()
+            rgba, scan = t.read_rgba(), t.read_png_scanlines()
+            assert scan.shape == (H, 4 * W + 1)
+            host, _ = _png_scanlines(bytes(vf._encode_png_rgba8(rgba)))
+            assert scan.tobytes() == host
+            if H > 64:                                         # rank 0 of 2 then holds only part of the frame
+                t.set_shard(0, 2, 64)
+                t.render()
+                with pytest.raises(cabi.VfError, match="whole frame"):
+                    t.read_png_scanlines()
+        finally:
+            t.close()
+    out = tmp_path / "big.png"
+    s = vf.Scene(1920, 1080, grid=512)
+    s.set_height_from_r32f(np.random.default_rng(3).random((512, 512), dtype=np.float32) * np.float32(0.5) - np.float32(0.25))
+    s.render_png(str(out))
+    assert np.array_equal(np.asarray(Image.open(out).convert("RGBA")), s.render_rgba())
+
+
 def test_height_argument_errors():
     scn = vf.Scene(64, 64, grid=8)
     with pytest.raises(RuntimeError, match="height must be C-contiguous"):

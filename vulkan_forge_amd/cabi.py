@@ -20,7 +20,7 @@ SYMBOLS = [
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
-    "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_visibility",
+    "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
@@ -63,6 +63,7 @@ _PROTOS = {
     "vf_terrain_render": (_i, [_vp, _vp]),
     "vf_terrain_sync": (_i, [_vp]),
     "vf_terrain_read_rgba": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_terrain_read_png_scanlines": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "vf_terrain_read_visibility": (_i, [_vp, _vp]),
     "vf_terrain_enable_timing": (_i, [_vp, _i]),
     "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
@@ -196,6 +197,13 @@ class Terrain:
         out = np.empty((rows, self.W, 4), np.uint8)
         self._check(self.lib.vf_terrain_read_rgba(self.t, out.ctypes.data, 0, rows))
         return out
+
+    def read_png_scanlines(self):
+        """(H, 4W+1) uint8 copy of the handle's pinned PNG scanlines (filter byte + filtered row) of the last frame."""
+        ptr, n = _vp(), C.c_size_t()
+        self._check(self.lib.vf_terrain_read_png_scanlines(self.t, C.byref(ptr), C.byref(n)))
+        buf = (C.c_uint8 * n.value).from_address(ptr.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.H, self.W * 4 + 1).copy()
 
     def read_visibility(self):
         out = np.empty((self.local_rows(), self.W), np.uint32)

@@ -101,6 +101,9 @@ struct vf_terrain {
     uint32_t *d_last_blocks = nullptr;   // feedback: blocks rasterised per tile in the previous frame (+ [ntiles] = mean)
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
+    uint8_t *d_png = nullptr, *h_png = nullptr;   // PNG scanlines of the last frame: device, pinned host
+    uint8_t *h_stage = nullptr;                   // 2 x kStageChunk pinned bytes: device -> pageable host copies go through here
+    hipEvent_t stage_ev[2] = { nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     bool shard_tiles = false;
     uint32_t local_tiles = 0;            // tiles this handle renders (= ntx * local tile rows unless tile-sharded)
@@ -302,6 +305,10 @@ void vf_terrain_destroy(vf_terrain *t)
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
                      t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
+    if (t->d_png) (void)hipFree(t->d_png);
+    if (t->h_png) (void)hipHostFree(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     delete t;
 }
@@ -534,6 +541,31 @@ int vf_terrain_sync(vf_terrain *t)
     return VF_OK;
 }
 
+// Device -> pageable host memory through two pinned staging chunks owned by the handle: the DMA of chunk k+1 overlaps the
+// host memcpy of chunk k, and nothing is allocated or registered per call (the reference maps a fresh buffer per call,
+// src/terrain/mod.rs:446-451).
+constexpr size_t kStageChunk = 8u << 20;
+static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
+{
+    if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
+    if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, 2 * kStageChunk, hipHostMallocDefault));
+    for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
+    for (size_t i = 0; i <= nchunks; ++i) {
+        if (i < nchunks) {
+            const size_t len = i + 1 == nchunks ? n - i * kStageChunk : kStageChunk;
+            VF_HIP_TRY(hipMemcpyAsync(t->h_stage + (i & 1) * kStageChunk, src + i * kStageChunk, len, hipMemcpyDeviceToHost, s));
+            VF_HIP_TRY(hipEventRecord(t->stage_ev[i & 1], s));
+        }
+        if (i > 0) {
+            const size_t k = i - 1, len = k + 1 == nchunks ? n - k * kStageChunk : kStageChunk;
+            VF_HIP_TRY(hipEventSynchronize(t->stage_ev[k & 1]));
+            std::memcpy(dst + k * kStageChunk, t->h_stage + (k & 1) * kStageChunk, len);
+        }
+    }
+    return VF_OK;
+}
+
 int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows)
 {
     if (!t || !dst) return fail(VF_ERR_INVALID, "NULL argument");
@@ -542,7 +574,26 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
     if ((uint64_t)y0 + rows > t->local_rows) return fail(VF_ERR_INVALID, "row range outside the local rows");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    VF_HIP_TRY(hipMemcpy(dst, t->d_rgba + (size_t)y0 * t->W, (size_t)rows * t->W * 4, hipMemcpyDeviceToHost));
+    return copy_to_host_staged(t, dst, (const uint8_t *)(t->d_rgba + (size_t)y0 * t->W), (size_t)rows * t->W * 4,
+                               t->last_stream ? t->last_stream : t->ctx->stream);
+}
+
+int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines, size_t *nbytes)
+{
+    if (!t || !host_scanlines || !nbytes) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    if (t->shard_tiles || t->local_rows != t->H) return fail(VF_ERR_INVALID, "PNG read-back needs the whole frame on one handle");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    const size_t n = ((size_t)t->W * 4 + 1) * t->H;
+    if (!t->d_png) VF_HIP_TRY(hipMalloc(&t->d_png, n));
+    if (!t->h_png) VF_HIP_TRY(hipHostMalloc(&t->h_png, n, hipHostMallocDefault));     // persistent: the reference allocates per call (:446-451)
+    hipStream_t s = t->last_stream ? t->last_stream : t->ctx->stream;
+    hipLaunchKernelGGL(k_png_filter, dim3(t->H), dim3(256), 0, s, (const uint32_t *)t->d_rgba, t->W, t->d_png);
+    VF_HIP_TRY(hipGetLastError());
+    VF_HIP_TRY(hipMemcpyAsync(t->h_png, t->d_png, n, hipMemcpyDeviceToHost, s));
+    VF_HIP_TRY(hipStreamSynchronize(s));
+    *host_scanlines = t->h_png;
+    *nbytes = n;
     return VF_OK;
 }
 

@@ -14,6 +14,7 @@
 //   k_grid_*          grid_generate (bit-exact make_grid)
 //   k_triangle        the triangle smoke path
 //   k_stitch_bands / k_stitch_tiles   multi-GPU de-interleave
+//   k_png_filter      render_png read-back: PNG scanline filtering
 //
 // Painter's order: the reference pipeline has no depth buffer (src/terrain/pipeline.rs:133), so the
 // visible fragment is the LAST covering front-facing primitive in index order == max primitive id.
@@ -1122,6 +1123,71 @@ __global__ void k_stitch_bands(const uint4 *__restrict__ src, uint4 *__restrict_
     uint32_t b = y >> band_shift, r = b % nranks;
     uint32_t ly = ((b / nranks) << band_shift) + (y & (band_h - 1u));
     dst[p] = src[((size_t)r * local_rows + ly) * row_vec4 + xq];
+}
+
+// ---------------------------------------------------------------------------------------------
+// render_png read-back (src/terrain/mod.rs:439-490): PNG scanline filtering on the device, so that the host only deflates.
+// One workgroup per row: pass 1 sums |signed residual| for the five PNG filters (None, Sub, Up, Average, Paeth), the
+// smallest wins (first on ties -- the same rule as the host encoder), pass 2 writes filter byte + residuals.  HBM-bound:
+// the row, its upper neighbour and the output once each.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t png_paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (uint32_t)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+}
+__device__ __forceinline__ uint32_t png_residual(int f, uint32_t x, uint32_t a, uint32_t b, uint32_t c)   // one byte
+{
+    switch (f) {
+    case 0: return x;
+    case 1: return (x - a) & 255u;
+    case 2: return (x - b) & 255u;
+    case 3: return (x - ((a + b) >> 1)) & 255u;
+    default: return (x - png_paeth((int)a, (int)b, (int)c)) & 255u;
+    }
+}
+__global__ __launch_bounds__(256) void k_png_filter(const uint32_t *__restrict__ rgba, uint32_t W, uint8_t *__restrict__ out)
+{
+    __shared__ uint32_t s_sum[5][4];
+    __shared__ uint32_t s_best;
+    const uint32_t y = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *cur = rgba + (size_t)y * W, *up = y ? cur - W : nullptr;
+    uint32_t sums[5] = { 0, 0, 0, 0, 0 };
+    for (uint32_t x = tid; x < W; x += 256) {
+        const uint32_t px = cur[x], pa = x ? cur[x - 1] : 0u, pb = up ? up[x] : 0u, pc = (up && x) ? up[x - 1] : 0u;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const uint32_t v = (px >> (8 * ch)) & 255u, a = (pa >> (8 * ch)) & 255u, b = (pb >> (8 * ch)) & 255u, c = (pc >> (8 * ch)) & 255u;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) { const uint32_t r = png_residual(f, v, a, b, c); sums[f] += r < 128u ? r : 256u - r; }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        uint32_t v = sums[f];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63u) == 0) s_sum[f][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t best = 0, best_sum = 0xFFFFFFFFu;          // row sums stay below 2^32: 4 * 65536 * 128 at the widest frame
+        for (int f = 0; f < 5; ++f) {
+            const uint32_t v = s_sum[f][0] + s_sum[f][1] + s_sum[f][2] + s_sum[f][3];
+            if (v < best_sum) { best_sum = v; best = (uint32_t)f; }
+        }
+        s_best = best;
+    }
+    __syncthreads();
+    const int f = (int)s_best;
+    uint8_t *dst = out + (size_t)y * ((size_t)W * 4 + 1);
+    if (tid == 0) dst[0] = (uint8_t)f;
+    for (uint32_t x = tid; x < W; x += 256) {
+        const uint32_t px = cur[x], pa = x ? cur[x - 1] : 0u, pb = up ? up[x] : 0u, pc = (up && x) ? up[x - 1] : 0u;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+            dst[1 + 4 * (size_t)x + ch] = (uint8_t)png_residual(f, (px >> (8 * ch)) & 255u, (pa >> (8 * ch)) & 255u, (pb >> (8 * ch)) & 255u,
+                                                               (pc >> (8 * ch)) & 255u);
+    }
 }
 
 // multi-GPU, tile shards: [nranks][stride_tiles][64][64] rank-major gather buffer -> (H, W) image.  Tile (tx, ty) belongs

@@ -155,18 +155,20 @@ public:
         check(vf_terrain_set_height(t, static_cast<const float *>(arr.data()), w, h));
     }
 
+    void render_into(uint8_t *dst, uint32_t rows)
+    {
+        py::gil_scoped_release nogil;
+        int rc = vf_terrain_render(t, nullptr);
+        if (rc == VF_OK) rc = vf_terrain_read_rgba(t, dst, 0, rows);
+        if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
+    }
     std::vector<uint8_t> render_pixels()
     {
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
-        std::vector<uint8_t> px((size_t)rows * W * 4);
-        {
-            py::gil_scoped_release nogil;
-            int rc = vf_terrain_render(t, nullptr);
-            if (rc == VF_OK) rc = vf_terrain_read_rgba(t, px.data(), 0, rows);
-            if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
-        }
-        return px;
+        std::unique_ptr<uint8_t[]> raw(new uint8_t[(size_t)rows * W * 4]);     // not value-initialised: every byte is overwritten
+        render_into(raw.get(), rows);
+        return std::vector<uint8_t>(raw.get(), raw.get() + (size_t)rows * W * 4);
     }
 
     // render_png, src/terrain/mod.rs:409-491, src/scene/mod.rs:278-335
@@ -174,9 +176,20 @@ public:
     {
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
-        std::vector<uint8_t> px = render_pixels();
+        if (rows != H) {                                       // band-sharded handle: its rows only, filtered on the host
+            std::vector<uint8_t> px = render_pixels();
+            py::gil_scoped_release nogil;
+            write_png_rgba8(path, px.data(), W, rows);
+            return;
+        }
+        // whole frame: the GPU filters the scanlines into pinned host memory, the host deflates them in parallel
         py::gil_scoped_release nogil;
-        write_png_rgba8(path, px.data(), W, rows);
+        const uint8_t *scan = nullptr;
+        size_t nbytes = 0;
+        int rc = vf_terrain_render(t, nullptr);
+        if (rc == VF_OK) rc = vf_terrain_read_png_scanlines(t, &scan, &nbytes);
+        if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
+        write_png_scanlines(path, scan, W, H);
     }
 
     // extension (not in the reference): the frame as (H, W, 4) uint8 without the PNG round trip
@@ -184,9 +197,8 @@ public:
     {
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
-        std::vector<uint8_t> px = render_pixels();
         py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
-        std::memcpy(a.mutable_data(), px.data(), px.size());
+        render_into(a.mutable_data(), rows);                   // straight into the array: no intermediate copy
         return a;
     }
     // extension: visible primitive id + 1 per pixel of the last render (0 = background)
