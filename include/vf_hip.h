@@ -99,6 +99,14 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
 /* same, borrowing a texture already resident in HBM (e.g. a torch tensor's data_ptr) */
 int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_t tw, uint32_t th);
 
+/* Fragment-stage variant.  VF_SHADE_REFERENCE (default) is fs_main as coded (src/shaders/terrain.wgsl:69-91): analytic
+ * normals, no tonemap -- the only mode for which parity with the reference is claimed.  VF_SHADE_SPEC_T32 is the stage the
+ * reference documents but never implemented (ROADMAP.md:421-436 forward-difference normals from the height texture;
+ * README.md:128,174-175 Reinhard in linear before the sRGB store); it is validated against this build's oracle only. */
+#define VF_SHADE_REFERENCE 0
+#define VF_SHADE_SPEC_T32 1
+int vf_terrain_set_shade_mode(vf_terrain *t, int mode);
+
 /* Multi-GPU screen split (new; the reference is single-device).  Pixel row y belongs to this
  * object iff ((y / band_h) % nranks) == rank; owned rows are stored densely ("local rows") in
  * band order.  band_h must be a power of two.  Default: rank 0 of 1 (all rows). */

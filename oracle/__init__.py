@@ -65,6 +65,7 @@ def _load() -> C.CDLL:
     lib.vfo_build_grid_xyuv.argtypes = [C.c_uint32, _f32p, _u32p]
     lib.vfo_render_terrain.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _f32p, C.c_uint32, C.c_uint32,
                                        _u8p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, _u32p, C.c_int]
+    lib.vfo_render_terrain_mode.argtypes = lib.vfo_render_terrain.argtypes + [C.c_int]
     lib.vfo_render_triangle.argtypes = [C.c_uint32, C.c_uint32, _u8p]
     lib.vfo_raster_triangles.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
     lib.vfo_dem_ingest_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float]
@@ -191,9 +192,13 @@ def build_grid_xyuv(n):
     return verts, idx
 
 
+SHADE_REFERENCE, SHADE_SPEC_T32 = 0, 1
+
+
 def render_terrain(u, W, H, grid, height, lut_rgba8, lut_is_srgb=True, rank=0, nranks=1, band_h=64,
-                   want_vis=True, nthreads=1):
-    """Returns (rgba (H,W,4) u8, vis (H,W) u32 or None). vis = primitive id + 1, 0 = background."""
+                   want_vis=True, nthreads=1, shade_mode=SHADE_REFERENCE):
+    """Returns (rgba (H,W,4) u8, vis (H,W) u32 or None). vis = primitive id + 1, 0 = background.
+    shade_mode SHADE_SPEC_T32 = the documented-but-unimplemented fragment stage (see frag_terrain in vf_oracle.c)."""
     u = np.ascontiguousarray(u, dtype=np.float32)
     assert u.shape == (44,)
     height = np.ascontiguousarray(height, dtype=np.float32)
@@ -201,9 +206,9 @@ def render_terrain(u, W, H, grid, height, lut_rgba8, lut_is_srgb=True, rank=0, n
     lut = np.ascontiguousarray(lut_rgba8, dtype=np.uint8).reshape(1024)
     rgba = np.empty((H, W, 4), np.uint8)
     vis = np.empty((H, W), np.uint32)
-    rc = lib().vfo_render_terrain(_p(u, _f32p), W, H, grid, _p(height, _f32p), height.shape[1], height.shape[0],
-                                  _p(lut, _u8p), int(bool(lut_is_srgb)), rank, nranks, band_h,
-                                  _p(rgba, _u8p), _p(vis, _u32p), int(nthreads))
+    rc = lib().vfo_render_terrain_mode(_p(u, _f32p), W, H, grid, _p(height, _f32p), height.shape[1], height.shape[0],
+                                       _p(lut, _u8p), int(bool(lut_is_srgb)), rank, nranks, band_h,
+                                       _p(rgba, _u8p), _p(vis, _u32p), int(nthreads), int(shade_mode))
     if rc != 0:
         raise MemoryError("oracle allocation failed")
     return rgba, (vis if want_vis else None)

@@ -411,6 +411,10 @@ typedef struct {
     int mode;             /* 0 terrain fs_main, 1 triangle fs_main */
     float h_range, exposure, Lx, Ly, Lz;
     float lut[256][3];
+    /* SPEC_T32 fragment mode (no reference implementation, see frag_terrain) */
+    int shade_mode;       /* 0 REFERENCE = what terrain.wgsl does, 1 SPEC_T32 = what ROADMAP.md T3.2 / README.md describe */
+    const float *tex; uint32_t tw, th;
+    float spacing, exag;
 } rtarget;
 
 typedef void (*frag_fn)(const rtarget *, const float attr[3], uint8_t out[4]);
@@ -428,11 +432,37 @@ static void frag_terrain(const rtarget *rt, const float attr[3], uint8_t out[4])
     int i0 = (int)i0f, i1 = i0 + 1;
     i0 = i0 < 0 ? 0 : (i0 > 255 ? 255 : i0);
     i1 = i1 < 0 ? 0 : (i1 > 255 ? 255 : i1);
-    float dhdx = 1.3f * o_cosf(x * 1.3f) * 0.25f;                          /* :79 */
-    float dhdz = -1.1f * o_sinf(z * 1.1f) * 0.25f;                         /* :80 */
-    float d = fmaf(dhdz, dhdz, fmaf(dhdx, dhdx, 1.0f));
-    float inv = 1.0f / sqrtf(d);                                           /* normalize :81 */
-    float nx = -dhdx * inv, ny = inv, nz = -dhdz * inv;
+    float nx, ny, nz;
+    if (rt->shade_mode == 0) {
+        float dhdx = 1.3f * o_cosf(x * 1.3f) * 0.25f;                      /* :79 */
+        float dhdz = -1.1f * o_sinf(z * 1.1f) * 0.25f;                     /* :80 */
+        float d = fmaf(dhdz, dhdz, fmaf(dhdx, dhdx, 1.0f));
+        float inv = 1.0f / sqrtf(d);                                       /* normalize :81 */
+        nx = -dhdx * inv; ny = inv; nz = -dhdz * inv;
+    } else {
+        /* SPEC_T32 -- the fragment stage the reference DOCUMENTS but does not implement (ROADMAP.md:421-436,
+         * README.md:128,174-175): forward-difference normals from the height texture, Lambert + ambient, LUT, Reinhard in
+         * linear, sRGB store.  No reference code exists for it; these are this build's choices, checked only HIP <-> oracle:
+         *  - uv from the interpolated xz varying (the mesh spans [-1.5, 1.5]: u = x/3 + 1/2);
+         *  - h, hx, hy = nearest texels at uv, uv + (1/(Tw-1), 0), uv + (0, 1/(Th-1)) (ROADMAP.md:427-429), texture only;
+         *  - tangents (spacing, (hx-h)*exag, 0) and (0, (hy-h)*exag, spacing) in the Y-up world, normal = their upward
+         *    cross product (the ROADMAP snippet's cross(dpy, dpx) points down in its own z-up frame; "sun from the east
+         *    lights the east slopes" :433 needs the upward one). */
+        const float third = 1.0f / 3.0f;
+        float uu = fmaf(x, third, 0.5f), vv = fmaf(z, third, 0.5f);
+        float du = 1.0f / (float)((rt->tw > 2u ? rt->tw : 2u) - 1u), dv = 1.0f / (float)((rt->th > 2u ? rt->th : 2u) - 1u);
+        int tx0 = (int)floorf(uu * (float)rt->tw), tx1 = (int)floorf((uu + du) * (float)rt->tw);
+        int ty0 = (int)floorf(vv * (float)rt->th), ty1 = (int)floorf((vv + dv) * (float)rt->th);
+        int mx = (int)rt->tw - 1, my = (int)rt->th - 1;
+        tx0 = tx0 < 0 ? 0 : (tx0 > mx ? mx : tx0); tx1 = tx1 < 0 ? 0 : (tx1 > mx ? mx : tx1);
+        ty0 = ty0 < 0 ? 0 : (ty0 > my ? my : ty0); ty1 = ty1 < 0 ? 0 : (ty1 > my ? my : ty1);
+        float h0 = rt->tex[(size_t)ty0 * rt->tw + tx0], hx = rt->tex[(size_t)ty0 * rt->tw + tx1], hy = rt->tex[(size_t)ty1 * rt->tw + tx0];
+        float ax = (hx - h0) * rt->exag, az = (hy - h0) * rt->exag, sp = rt->spacing;
+        float vx = -(ax * sp), vy = sp * sp, vz = -(sp * az);
+        float d = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+        float inv = 1.0f / sqrtf(d);
+        nx = vx * inv; ny = vy * inv; nz = vz * inv;
+    }
     float ndl = fmaf(nz, rt->Lz, fmaf(ny, rt->Ly, nx * rt->Lx));
     float lambert = fminf(fmaxf(ndl, 0.0f), 1.0f);                         /* :84 */
     float shade = 0.15f * (1.0f - lambert) + lambert;                      /* mix(.15,1,lambert) :88 */
@@ -440,6 +470,7 @@ static void frag_terrain(const rtarget *rt, const float attr[3], uint8_t out[4])
         float l0 = rt->lut[i0][ch], l1 = rt->lut[i1][ch];
         float lc = fmaf(f, l1 - l0, l0);
         float v = lc * rt->exposure * shade;                               /* :90 */
+        if (rt->shade_mode != 0) v = v / (1.0f + v);                       /* Reinhard, tests/test_tonemap.py:7-8, in linear (README.md:128) */
         out[ch] = srgb_encode(v);
     }
     out[3] = 255;
@@ -663,11 +694,24 @@ static void terrain_prim(const vsctx *vc, uint32_t prim, cvert t[3])
  * vis (W*H u32, required): surviving primitive id + 1 per pixel, 0 = background.
  * Returns 0, or -1 on allocation failure.
  */
+VFO_API int vfo_render_terrain_mode(const float u[44], uint32_t W, uint32_t H, uint32_t grid,
+                                    const float *height, uint32_t tw, uint32_t th,
+                                    const uint8_t lut_rgba8[1024], int lut_is_srgb,
+                                    uint32_t rank, uint32_t nranks, uint32_t band_h,
+                                    uint8_t *rgba, uint32_t *vis, int nthreads, int shade_mode);
 VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32_t grid,
                                const float *height, uint32_t tw, uint32_t th,
                                const uint8_t lut_rgba8[1024], int lut_is_srgb,
                                uint32_t rank, uint32_t nranks, uint32_t band_h,
                                uint8_t *rgba, uint32_t *vis, int nthreads)
+{
+    return vfo_render_terrain_mode(u, W, H, grid, height, tw, th, lut_rgba8, lut_is_srgb, rank, nranks, band_h, rgba, vis, nthreads, 0);
+}
+VFO_API int vfo_render_terrain_mode(const float u[44], uint32_t W, uint32_t H, uint32_t grid,
+                                    const float *height, uint32_t tw, uint32_t th,
+                                    const uint8_t lut_rgba8[1024], int lut_is_srgb,
+                                    uint32_t rank, uint32_t nranks, uint32_t band_h,
+                                    uint8_t *rgba, uint32_t *vis, int nthreads, int shade_mode)
 {
     init_tables();
     uint32_t n = grid < 2 ? 2 : grid;
@@ -675,6 +719,8 @@ VFO_API int vfo_render_terrain(const float u[44], uint32_t W, uint32_t H, uint32
     rtarget rt;
     setup_target(&rt, W, H, rgba, vis, rank, nranks, band_h);
     rt.mode = 0;
+    rt.shade_mode = shade_mode; rt.tex = height; rt.tw = tw; rt.th = th;
+    rt.spacing = fmaxf(u[36], 1e-8f); rt.exag = u[38];
     rt.h_range = fmaxf(u[37], 1e-8f);                                    /* terrain.wgsl:71 */
     rt.exposure = u[35];
     {   /* L = normalize(sun) terrain.wgsl:83 */

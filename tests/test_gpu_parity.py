@@ -25,10 +25,11 @@ def cabi():
     return C
 
 
-def hip_frame(cabi, u, W, H, G, height, lut, srgb=True, shard=None):
+def hip_frame(cabi, u, W, H, G, height, lut, srgb=True, shard=None, shade_mode=0):
     t = cabi.Terrain(W, H, G, lut, lut_is_srgb=srgb)
     try:
         t.set_uniforms(u)
+        t.set_shade_mode(shade_mode)
         if height is not None:
             t.set_height(height)
         if shard:
@@ -50,6 +51,20 @@ def assert_parity(rgba, vis, ref_rgba, ref_vis):
     d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max()
     assert d <= RGBA_TOL, f"RGBA differs by {d} LSB"
     return int(d)
+
+
+# ---- SPEC_T32 fragment mode: HIP == oracle, bit for bit ------------------------------------------
+@pytest.mark.parametrize("W,H,G,tex,cam", [(320, 240, 64, (64, 64), None), (200, 150, 40, (13, 61), None), (160, 120, 32, (1, 1), None),
+                                           (256, 256, 128, (128, 128), "fill"), (1920, 1080, 1024, (1024, 1024), None)])
+def test_spec_t32_mode_matches_the_oracle(cabi, oracle, luts, W, H, G, tex, cam):
+    h = heightmap(G + tex[0], tex[0], tex[1])
+    u = oracle.default_uniforms(1, W, H) if cam is None else oracle.look_at_uniforms(1, W, H, *FILL_CAMERA)
+    u[38] = 1.7                                                         # exaggeration enters the forward differences
+    rgba, vis = hip_frame(cabi, u, W, H, G, h, luts["terrain"], shade_mode=1)
+    ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["terrain"], shade_mode=oracle.SHADE_SPEC_T32, nthreads=8)
+    assert_parity(rgba, vis, ref_rgba, ref_vis)
+    plain, _ = oracle.render_terrain(u, W, H, G, h, luts["terrain"], nthreads=8)
+    assert not np.array_equal(plain, ref_rgba)                           # and it is a different image from REFERENCE mode
 
 
 # ---- committed golden vectors --------------------------------------------------------------------------

@@ -133,3 +133,43 @@ def test_threads_and_shards_do_not_change_the_frame(oracle, luts, kind, cam):
             out[rows] = rr[rows]
             assert (rr[~rows] == np.array([39, 39, 48, 255], np.uint8)).all()
         assert np.array_equal(out, r1)
+
+
+# ---- SPEC_T32: the documented-but-unimplemented fragment stage ----------------------------------
+def test_spec_t32_fragment_mode_properties(oracle, luts):
+    """No reference code exists for this mode (ROADMAP.md:421-436, README.md:128,174-175), so the oracle is checked
+    against the properties the documents state: same geometry, normals from the height TEXTURE (forward differences),
+    'sun from the east lights the east slopes', Reinhard x/(1+x) in linear before the sRGB store."""
+    W, H, G = 160, 120, 48
+    lut = luts["viridis"]
+    cam = ((0.0, 4.0, 0.01), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0), 45.0, 0.1, 100.0)       # top-down: +x is east on screen
+    u = oracle.look_at_uniforms(1, W, H, *cam)
+    flat = np.zeros((8, 8), np.float32)
+    ref, vis = oracle.render_terrain(u, W, H, G, flat, lut)
+    spec, vis2 = oracle.render_terrain(u, W, H, G, flat, lut, shade_mode=oracle.SHADE_SPEC_T32)
+    assert np.array_equal(vis, vis2)                                   # the mode only changes colours
+    cov = vis > 0
+    # flat texture: n = (0,1,0) everywhere -> shade is one constant; colour = reinhard(lut(height) * shade)
+    L = np.float32(u[33]) / np.sqrt(np.float32((u[32:35] ** 2).sum()))
+    shade = np.float32(0.15) * (np.float32(1) - L) + L
+    eotf = lambda b: np.where(b <= 0.04045 * 255, b / 255 / 12.92, ((b / 255 + 0.055) / 1.055) ** 2.4)
+    # REFERENCE shades with the analytic normal, SPEC with the flat one: undo each and compare the LUT colour
+    lin_spec = eotf(spec[cov][:, :3].astype(np.float64))
+    unre = lin_spec / np.maximum(1.0 - lin_spec, 1e-6) / shade          # inverse Reinhard, inverse shade
+    assert unre.max() < 1.05 and lin_spec.max() < 0.5                  # x/(1+x) of values <= 1 stays below 1/2
+    # east-facing ramp: heights rise towards -x (west), so the slope faces east (+x)
+    ramp = np.repeat(np.linspace(1.5, -1.5, 8, dtype=np.float32)[None, :], 8, axis=0)     # -0.43 per texel: a 23 degree slope
+    east = u.copy(); west = u.copy()
+    east[32:35] = [1.0, 0.35, 0.0]; west[32:35] = [-1.0, 0.35, 0.0]
+    a, va = oracle.render_terrain(east, W, H, G, ramp, lut, shade_mode=oracle.SHADE_SPEC_T32)
+    b, vb = oracle.render_terrain(west, W, H, G, ramp, lut, shade_mode=oracle.SHADE_SPEC_T32)
+    assert np.array_equal(va, vb)
+    m = va > 0
+    assert a[m][:, :3].astype(int).sum() > 1.5 * b[m][:, :3].astype(int).sum()     # lit vs. ambient only
+    # mirrored ramp (slope faces west): the same two suns swap roles
+    c, vc = oracle.render_terrain(west, W, H, G, ramp[:, ::-1].copy(), lut, shade_mode=oracle.SHADE_SPEC_T32)
+    d, vd = oracle.render_terrain(east, W, H, G, ramp[:, ::-1].copy(), lut, shade_mode=oracle.SHADE_SPEC_T32)
+    assert c[vc > 0][:, :3].astype(int).sum() > 1.3 * d[vd > 0][:, :3].astype(int).sum()
+    # degenerate 1x1 texture: forward differences vanish, no out-of-range fetch
+    one, _ = oracle.render_terrain(u, W, H, G, np.zeros((1, 1), np.float32), lut, shade_mode=oracle.SHADE_SPEC_T32)
+    assert np.array_equal(one, spec)

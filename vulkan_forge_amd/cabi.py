@@ -18,7 +18,7 @@ VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -
 SYMBOLS = [
     "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
-    "vf_terrain_set_height_device", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
+    "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
@@ -52,6 +52,7 @@ _PROTOS = {
     "vf_terrain_set_uniforms": (_i, [_vp, _vp]),
     "vf_terrain_set_height": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_set_height_device": (_i, [_vp, _vp, _u32, _u32]),
+    "vf_terrain_set_shade_mode": (_i, [_vp, _i]),
     "vf_terrain_set_shard": (_i, [_vp, _u32, _u32, _u32]),
     "vf_terrain_local_rows": (_i, [_vp, C.POINTER(_u32)]),
     "vf_terrain_set_tile_shard": (_i, [_vp, _u32, _u32, _u32]),
@@ -154,6 +155,10 @@ class Terrain:
 
     def set_height_device(self, dptr, tw, th):
         self._check(self.lib.vf_terrain_set_height_device(self.t, _vp(dptr), tw, th))
+
+    def set_shade_mode(self, mode):
+        """0 = REFERENCE (terrain.wgsl as coded), 1 = SPEC_T32 (documented-only stage; oracle-validated)."""
+        self._check(self.lib.vf_terrain_set_shade_mode(self.t, int(mode)))
 
     def set_shard(self, rank, nranks, band_h=64):
         self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))

@@ -51,6 +51,8 @@ struct FrameParams {
     uint32_t shard_tiles;           // 0: whole frame / row bands (local rows, row-major); 1: interleaved tiles (tile-major)
     const uint32_t *tile_map;       // shard_tiles: local tile -> tx | ty << 16
     uint32_t clear_rgba;            // packed sRGB8 clear colour
+    uint32_t shade_mode;            // 0 REFERENCE (terrain.wgsl as coded), 1 SPEC_T32 (the documented fragment stage)
+    const float *tex;               // height texture (SPEC_T32 normals)
 };
 
 // inclusive pixel rectangle (clamped to the target) a grid block, or a whole block row, may touch; x0 > x1 = empty

@@ -106,6 +106,7 @@ struct vf_terrain {
     hipEvent_t stage_ev[2] = { nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     bool shard_tiles = false;
+    uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
     uint32_t local_tiles = 0;            // tiles this handle renders (= ntx * local tile rows unless tile-sharded)
     uint32_t *d_rgba = nullptr;
     uint32_t *d_vis = nullptr;           // only allocated for vf_terrain_read_visibility
@@ -361,6 +362,14 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
     return VF_OK;
 }
 
+int vf_terrain_set_shade_mode(vf_terrain *t, int mode)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (mode != VF_SHADE_REFERENCE && mode != VF_SHADE_SPEC_T32) return fail(VF_ERR_INVALID, "unknown shade mode");
+    t->shade_mode = (uint32_t)mode;
+    return VF_OK;
+}
+
 int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
@@ -476,6 +485,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
     P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map;
+    P.shade_mode = t->shade_mode; P.tex = t->d_height;
     const SrgbTables &T = tables();
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
 }

@@ -379,11 +379,30 @@ __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const 
     float f = c - i0f;
     int i0 = (int)i0f, i1 = i0 + 1;
     i0 = min(max(i0, 0), 255); i1 = min(max(i1, 0), 255);
-    float dhdx = 1.3f * det_cos(x * 1.3f) * 0.25f;
-    float dhdz = -1.1f * det_sin(z * 1.1f) * 0.25f;
-    float d = fmaf(dhdz, dhdz, fmaf(dhdx, dhdx, 1.0f));
-    float inv = 1.0f / sqrtf(d);
-    float nx = -dhdx * inv, ny = inv, nz = -dhdz * inv;
+    float nx, ny, nz;
+    if (P.shade_mode == 0u) {
+        float dhdx = 1.3f * det_cos(x * 1.3f) * 0.25f;
+        float dhdz = -1.1f * det_sin(z * 1.1f) * 0.25f;
+        float d = fmaf(dhdz, dhdz, fmaf(dhdx, dhdx, 1.0f));
+        float inv = 1.0f / sqrtf(d);
+        nx = -dhdx * inv; ny = inv; nz = -dhdz * inv;
+    } else {
+        // SPEC_T32: the fragment stage the reference documents but does not implement (ROADMAP.md:421-436, README.md:128,
+        // 174-175) -- forward-difference normals from the height texture, Reinhard in linear.  There is no reference code
+        // to follow; the choices are listed in DESIGN.md section 4 and the CPU checker restates them in the same order.
+        const float third = 1.0f / 3.0f;
+        const float uu = fmaf(x, third, 0.5f), vv = fmaf(z, third, 0.5f);
+        const float du = 1.0f / (float)(max(P.tw, 2u) - 1u), dv = 1.0f / (float)(max(P.th, 2u) - 1u);
+        const int mx = (int)P.tw - 1, my = (int)P.th - 1;
+        const int tx0 = min(max((int)floorf(uu * (float)P.tw), 0), mx), tx1 = min(max((int)floorf((uu + du) * (float)P.tw), 0), mx);
+        const int ty0 = min(max((int)floorf(vv * (float)P.th), 0), my), ty1 = min(max((int)floorf((vv + dv) * (float)P.th), 0), my);
+        const float h0 = P.tex[(size_t)ty0 * P.tw + tx0], hx = P.tex[(size_t)ty0 * P.tw + tx1], hy = P.tex[(size_t)ty1 * P.tw + tx0];
+        const float ax = (hx - h0) * P.exag, az = (hy - h0) * P.exag, sp = P.spacing;
+        const float vx = -(ax * sp), vy = sp * sp, vz = -(sp * az);
+        const float d = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+        const float inv = 1.0f / sqrtf(d);
+        nx = vx * inv; ny = vy * inv; nz = vz * inv;
+    }
     float ndl = fmaf(nz, P.Lz, fmaf(ny, P.Ly, nx * P.Lx));
     float lambert = fminf(fmaxf(ndl, 0.0f), 1.0f);
     float shade = 0.15f * (1.0f - lambert) + lambert;
@@ -393,6 +412,7 @@ __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const 
         float l0 = S.lut[i0 * 3 + ch], l1 = S.lut[i1 * 3 + ch];
         float lc = fmaf(f, l1 - l0, l0);
         float v = lc * P.exposure * shade;
+        if (P.shade_mode != 0u) v = v / (1.0f + v);          // Reinhard (tests/test_tonemap.py:7-8), before the sRGB store
         out |= srgb_encode(v, S.thresh) << (8 * ch);
     }
     return out;

@@ -212,6 +212,13 @@ public:
     }
     // extension: multi-GPU band ownership (DESIGN.md "Sharding")
     void set_shard(uint32_t rank, uint32_t nranks, uint32_t band_h) { check(vf_terrain_set_shard(t, rank, nranks, band_h)); }
+    // extension: "reference" = fs_main as coded; "spec_t32" = the documented-only stage (forward-difference normals + Reinhard)
+    void set_shade_mode(const std::string &mode)
+    {
+        if (mode == "reference") check(vf_terrain_set_shade_mode(t, VF_SHADE_REFERENCE));
+        else if (mode == "spec_t32") check(vf_terrain_set_shade_mode(t, VF_SHADE_SPEC_T32));
+        else throw py::value_error("shade mode must be 'reference' or 'spec_t32'");
+    }
     py::dict last_timings()
     {
         vf_timings tm;
@@ -491,6 +498,7 @@ py::class_<T> bind_terrain(py::module_ &m, const char *name)
         .def("debug_lut_format", &T::debug_lut_format)
         .def("debug_visibility", &T::debug_visibility)
         .def("set_shard", &T::set_shard, py::arg("rank"), py::arg("nranks"), py::arg("band_h") = 64)
+        .def("set_shade_mode", &T::set_shade_mode, py::arg("mode"))
         .def("enable_timing", &T::enable_timing, py::arg("on") = true)
         .def("last_timings", &T::last_timings);
 }
