@@ -164,3 +164,28 @@ def test_diagnostics():
     p = vf.device_probe()
     assert p["status"] == "ok" and p["millis"] >= 0 and p["backend_request"] == "AUTO"
     assert vf.device_probe("vulkan")["status"] == "unsupported"
+
+
+# ---- CLI tools -----------------------------------------------------------------------------------
+def test_cli_tools_on_the_gpu(tmp_path):
+    import json
+    from PIL import Image
+    from vulkan_forge_amd.tools import determinism_harness, device_diagnostics, perf_sanity, terrain_spike
+    assert terrain_spike.main(["--width", "200", "--height", "120", "--grid", "48", "--out", str(tmp_path / "t.png")]) == 0
+    assert Image.open(tmp_path / "t.png").size == (200, 120)
+    for workload in ("triangle", "terrain", "scene"):
+        rep_path = tmp_path / f"perf_{workload}.json"
+        assert perf_sanity.main(["--width", "160", "--height", "96", "--runs", "5", "--warmups", "1", "--workload", workload,
+                                 "--grid", "32", "--json", str(rep_path)]) == 0
+        rep = json.loads(rep_path.read_text())
+        assert rep["runs"] == 5 and len(rep["steady"]["samples_ms"]) == 5 and rep["init_ms"] > 0
+        assert rep["steady"]["min_ms"] <= rep["steady"]["median_ms"] <= rep["steady"]["p95_ms"] <= rep["steady"]["max_ms"]
+    for workload, procs in (("triangle", 0), ("terrain", 0), ("terrain", 2)):
+        out = tmp_path / f"det_{workload}_{procs}"
+        assert determinism_harness.main(["--width", "96", "--height", "64", "--runs", "3", "--processes", str(procs), "--png",
+                                         "--workload", workload, "--grid", "24", "--out-dir", str(out)]) == 0
+        rep = json.loads((out / "determinism_report.json").read_text())
+        assert rep["all_equal"] and len(rep["hashes"]) == 3 and len(rep["unique"]) == 1 and "png" in rep
+    assert device_diagnostics.main(["--json", str(tmp_path / "diag.json")]) == 0
+    diag = json.loads((tmp_path / "diag.json").read_text())
+    assert diag["backends"]["hip"]["adapters"] and diag["errors"] == []
