@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
                                                      uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi)
 {
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
+    __shared__ uint32_t s_lo[kMaxTileCols], s_hi[kMaxTileCols];   // this block row's [first, last+1) block per tile column
     const uint32_t by = blockIdx.x;
     if (threadIdx.x == 0) { s_rr[0] = 0x7FFF; s_rr[1] = 0x7FFF; s_rr[2] = -1; s_rr[3] = -1; }
+    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { s_lo[tc] = 0xFFFFFFFFu; s_hi[tc] = 0u; }
     __syncthreads();
     for (uint32_t bx = threadIdx.x; bx < P.nb; bx += 256) {
         const uint32_t b = by * P.nb + bx;
@@ -159,16 +161,18 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
         cap_seg[b] = seg; cap_rad[b] = rad;
         if (r.x0 <= r.x1) {
             // which blocks of this row can reach tile column tc?  [rc_lo, rc_hi) lets the tile kernel test a handful of
-            // blocks per row instead of all nb (arrays are reset to 0xFFFFFFFF / 0 before the launch)
+            // blocks per row instead of all nb.  One workgroup owns the whole block row, so the ranges are reduced in LDS
+            // (global atomics on these 32 K words cost more than the rest of the kernel).
             for (uint32_t tc = (uint32_t)r.x0 / kTileW; tc <= (uint32_t)r.x1 / kTileW; ++tc) {
-                atomicMin(&rc_lo[by * P.ntx + tc], bx);
-                atomicMax(&rc_hi[by * P.ntx + tc], bx + 1u);
+                atomicMin(&s_lo[tc], bx);
+                atomicMax(&s_hi[tc], bx + 1u);
             }
             atomicMin(&s_rr[0], (int)r.x0); atomicMin(&s_rr[1], (int)r.y0);
             atomicMax(&s_rr[2], (int)r.x1); atomicMax(&s_rr[3], (int)r.y1);
         }
     }
     __syncthreads();
+    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { rc_lo[by * P.ntx + tc] = s_lo[tc]; rc_hi[by * P.ntx + tc] = s_hi[tc]; }
     if (threadIdx.x == 0) {
         PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
