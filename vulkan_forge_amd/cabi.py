@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "libvf_hip.so")
+DEFAULT_LIB = os.environ.get("VF_HIP_LIB") or os.path.join(_HERE, "libvf_hip.so")     # override: kernel experiments only
 
 VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -3, -4
 

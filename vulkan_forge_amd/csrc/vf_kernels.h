@@ -700,15 +700,15 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: surviving triangles of the current block
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
     __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
-    __shared__ uint32_t s_cnt[kMaxSteps + 1];              // candidates per step, then exclusive offsets
+    __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
     __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
     __shared__ uint32_t s_firstid[kMaxSteps];
-    __shared__ uint16_t s_steprow[kMaxSteps];
+    __shared__ uint16_t s_allrows[1024];                   // block rows that reach the tile, descending (nb <= 1024)
     __shared__ uint32_t s_colfin[kTileW * 2];
     __shared__ uint32_t s_rowfin[kTileH * 2];
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
-    __shared__ uint32_t s_nrowsteps, s_nsteps, s_nlist, s_next, s_lock, s_done, s_frontier, s_published, s_blocks;
+    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks;
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
@@ -749,31 +749,32 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     }
     __syncthreads();
 
+    // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands word 15 - w ----
+    uint32_t nrows_total = 0;
+    {
+        uint32_t above = 0;                                // hit rows in the words above this wave's word
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t c = (uint32_t)__popcll(s_rows[w]);
+            nrows_total += c;
+            if (w > 15u - wave) above += c;
+        }
+        const unsigned long long m = s_rows[15u - wave];
+        const uint32_t b = 63u - lane;                     // lane 0 takes the highest row of the word
+        if ((m >> b) & 1ull) s_allrows[above + (uint32_t)__popcll(b == 63u ? 0ull : m >> (b + 1u))] = (uint16_t)((15u - wave) * 64u + b);
+    }
+    __syncthreads();
+
     const uint32_t hit_words = (P.nb + 63u) / 64u;
     volatile uint32_t *v_pending = s_pending;
     volatile uint32_t *v_done = &s_done, *v_frontier = &s_frontier, *v_published = &s_published;
 
-    for (;;) {
-        // ---- chunk set-up 1: wave 0 lists the next (up to kMaxSteps) block rows in descending order ----
-        if (wave == 0) {
-            uint32_t n = 0;
-            for (int32_t w = 15; w >= 0 && n < (uint32_t)kMaxSteps; --w) {
-                unsigned long long m = s_rows[w];
-                while (m && n < (uint32_t)kMaxSteps) {
-                    const int32_t rb = 63 - __builtin_clzll(m);
-                    m &= ~(1ull << rb);
-                    if (lane == 0) s_steprow[n] = (uint16_t)(w * 64 + rb);
-                    ++n;
-                }
-            }
-            if (lane == 0) { s_nrowsteps = n; s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
-        }
-        __syncthreads();
-        const uint32_t nrowsteps = s_nrowsteps;
-        if (nrowsteps == 0) break;                                  // uniform: nothing (left) to draw for this tile
-        // ---- chunk set-up 2: each wave tests the blocks of its rows against the tile; ballots are kept for the fill pass ----
+    for (uint32_t cursor = 0; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
+        // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
+        //      the ballots are kept for the fill pass ----
+        const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
+        if (tid == 0) { s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
         for (uint32_t k = wave; k < nrowsteps; k += kWaves) {
-            const uint32_t by = s_steprow[k];
+            const uint32_t by = s_allrows[cursor + k];
             const uint32_t bx_lo = rc_lo[by * P.ntx + tcol], bx_hi = rc_hi[by * P.ntx + tcol];   // only these can reach the tile column
             uint32_t cnt = 0;
             for (uint32_t g = 0; g < hit_words; ++g) {
@@ -791,49 +792,35 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
             if (lane == 0) { s_cnt[k] = cnt; s_firstid[k] = 2u * (by * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
         }
         __syncthreads();
-        // ---- chunk set-up 3: exclusive offsets; rows that do not fit the list wait for the next chunk ----
-        if (wave == 0) {
-            uint32_t run = 0, nfit = 0;
-            for (uint32_t base = 0; base < nrowsteps; base += 64) {       // 64 rows at a time: wave-wide inclusive scan
-                const uint32_t k = base + lane;
-                const uint32_t c = k < nrowsteps ? s_cnt[k] : 0u;
-                uint32_t inc = c;
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
-                const uint32_t excl = run + inc - c;
-                const bool fits = k < nrowsteps && excl + c <= kChunk;
-                if (k < nrowsteps) s_cnt[k] = excl;
-                const unsigned long long fm = __ballot(fits);
-                // rows are admitted in order: stop at the first one that does not fit
-                const uint32_t lead = fm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
-                nfit += lead;
-                run += __shfl(inc, 63);
-                if (lead < 64u) break;
-            }
-            if (lane == 0) {
-                s_nsteps = nfit;
-                s_nlist = nfit ? 0u : 0u;
-            }
+        // ---- chunk set-up 2: every wave scans the row counts for itself (two 64-row halves), so all agree on the list offsets
+        //      and on how many rows fit the list without another barrier; rows that do not fit wait for the next chunk ----
+        static_assert(kMaxSteps == 128, "the offset scan below handles two 64-row halves");
+        const uint32_t c0 = lane < nrowsteps ? s_cnt[lane] : 0u, c1 = lane + 64u < nrowsteps ? s_cnt[lane + 64u] : 0u;
+        uint32_t inc0 = c0, inc1 = c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t0 = __shfl_up(inc0, o), t1 = __shfl_up(inc1, o);
+            if (lane >= (uint32_t)o) { inc0 += t0; inc1 += t1; }
         }
-        __syncthreads();
-        const uint32_t nsteps = s_nsteps;                            // >= 1: a single row always fits (nb <= 1024 < kChunk)
-        // ---- chunk set-up 4: fill the work list from the kept ballots; retire the rows from the to-do mask ----
+        inc1 += __shfl(inc0, 63);
+        const unsigned long long fm0 = __ballot(lane < nrowsteps && inc0 <= kChunk), fm1 = __ballot(lane + 64u < nrowsteps && inc1 <= kChunk);
+        // rows are admitted in order: stop at the first one that does not fit (a single row always fits: nb <= 1024 < kChunk)
+        const uint32_t nsteps = fm0 != ~0ull ? (uint32_t)__builtin_ctzll(~fm0) : 64u + (fm1 != ~0ull ? (uint32_t)__builtin_ctzll(~fm1) : 64u);
+        const uint32_t nlist = nsteps <= 64u ? __shfl(inc0, (int)nsteps - 1) : __shfl(inc1, (int)nsteps - 65);
+        // ---- chunk set-up 3: fill the work list from the kept ballots ----
         for (uint32_t k = wave; k < nsteps; k += kWaves) {
-            const uint32_t by = s_steprow[k];
-            uint32_t pos = s_cnt[k], cnt = 0;
+            const uint32_t by = s_allrows[cursor + k];
+            uint32_t pos = k < 64u ? __shfl(inc0 - c0, (int)k) : __shfl(inc1 - c1, (int)k - 64), cnt = 0;
             for (uint32_t g = 0; g < hit_words; ++g) {
                 const unsigned long long m = s_hit[k][g];
                 if ((m >> lane) & 1ull) s_list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
                 const uint32_t c = (uint32_t)__popcll(m);
                 pos += c; cnt += c;
             }
-            if (lane == 0) {
-                s_pending[k] = cnt;
-                atomicAnd(reinterpret_cast<unsigned long long *>(&s_rows[by >> 6]), ~(1ull << (by & 63u)));
-                if (k == nsteps - 1) s_nlist = pos;
-            }
+            if (lane == 0) s_pending[k] = cnt;
         }
+        cursor += nsteps;
         __syncthreads();
-        const uint32_t nlist = s_nlist;
         VF_PH(0)
 
         // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
