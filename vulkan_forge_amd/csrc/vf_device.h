@@ -42,6 +42,7 @@ struct FrameParams {
     float h_range, exposure;        // max(u[37],1e-8), u[35]          (terrain.wgsl:71,85)
     float Lx, Ly, Lz;               // normalize(sun)                   (terrain.wgsl:83)
     float hw, hh;                   // 0.5*W, 0.5*H
+    float step;                     // grid pitch 3/(n-1): x_i = -1.5 + i*step (src/terrain/mod.rs:559-567), as k_axis_tables forms it
     uint32_t n, nm1;                // grid vertices per side, cells per side
     uint32_t nb;                    // blocks per side = ceil(nm1 / kBlockCells)
     uint32_t W, H;
@@ -147,6 +148,10 @@ __device__ __forceinline__ float cached_height(const float *__restrict__ hblk, u
 }
 
 struct ClipVert { float x, y, z, w, h; };
+
+// x_i (= z_j) recomputed with the very operations k_axis_tables used for AxisTables::xs: cheaper than a table load in the
+// tile kernel's vertex stage, identical bits
+__device__ __forceinline__ float grid_coord(const FrameParams &P, uint32_t i) { return -1.5f + (float)i * P.step; }
 
 // h for grid vertex (i, j) exactly as vs_main forms it (terrain.wgsl:50-55)
 __device__ __forceinline__ float displaced_height(const AxisTables &A, const float *__restrict__ tex, uint32_t tw, uint32_t i, uint32_t j)

@@ -480,6 +480,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
         P.Lx = sx * inv; P.Ly = sy * inv; P.Lz = sz * inv;
     }
     P.hw = 0.5f * (float)t->W; P.hh = 0.5f * (float)t->H;
+    P.step = (2.0f * 1.5f) / ((float)t->n - 1.0f);
     P.n = t->n; P.nm1 = t->n - 1; P.nb = t->nb;
     P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);

@@ -34,7 +34,7 @@ __global__ void k_axis_tables(uint32_t n, uint32_t tw, uint32_t th, float *xs, f
     const float scale = 1.5f;
     const float nm1f = (float)n - 1.0f;
     const float step = (2.0f * scale) / nm1f;          // src/terrain/mod.rs:559-560
-    float x = -scale + (float)i * step;                // :566-567
+    float x = -scale + (float)i * step;                // :566-567 (grid_coord() repeats exactly this)
     float uvc = (float)i / nm1f;                       // :568-569
     xs[i] = x;
     sinx[i] = det_sin(x * 1.3f);                       // terrain.wgsl:40
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                     uint32_t fl = F_BAD;
                     if (i < P.n && j < P.n) {
                         float rw;
-                        ClipVert cv = vertex_shader(P, A.xs[i], A.xs[j], hb[v]);
+                        ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), hb[v]);
                         fl = vertex_flags(cv);
                         if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
                     }
