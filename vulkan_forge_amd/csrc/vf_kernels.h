@@ -473,14 +473,13 @@ __device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, 
     return t0 <= t1 + 1e-4f;
 }
 
-__device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
-                                                   uint32_t idx, const TileCtx &T)
+__device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const float4 &cap_seg, float cap_rad, const TileCtx &T)
 {
     if (b.x0 > b.x1) return false;
     const int32_t x0 = max((int32_t)b.x0, T.px_lo), x1 = min((int32_t)b.x1, T.px_hi);
     const int32_t y0 = max((int32_t)b.y0, T.py_lo), y1 = min((int32_t)b.y1, T.py_hi);
     if (x0 > x1 || y0 > y1) return false;
-    if (!capsule_hits_tile(cap_seg[idx], cap_rad[idx], T)) return false;
+    if (!capsule_hits_tile(cap_seg, cap_rad, T)) return false;
     if (x1 - x0 <= y1 - y0) {
         const uint64_t seg = bit_range(y0 - T.py_lo, y1 - T.py_lo);
         for (int32_t c = x0 - T.px_lo; c <= x1 - T.px_lo; ++c)
@@ -773,23 +772,58 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         //      the ballots are kept for the fill pass ----
         const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
         if (tid == 0) { s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
-        for (uint32_t k = wave; k < nrowsteps; k += kWaves) {
-            const uint32_t by = s_allrows[cursor + k];
-            const uint32_t bx_lo = rc_lo[by * P.ntx + tcol], bx_hi = rc_hi[by * P.ntx + tcol];   // only these can reach the tile column
-            uint32_t cnt = 0;
-            for (uint32_t g = 0; g < hit_words; ++g) {
-                if (g * 64u + 63u < bx_lo || g * 64u >= bx_hi) { if (lane == 0) s_hit[k][g] = 0ull; continue; }   // uniform
-                const uint32_t bx = g * 64u + lane;
-                bool hit = false;
-                if (bx >= bx_lo && bx < bx_hi) {
-                    const uint32_t bidx = by * P.nb + bx;
-                    hit = block_is_candidate(boxes[bidx], cap_seg, cap_rad, bidx, T);
-                }
-                const unsigned long long m = __ballot(hit);
-                if (lane == 0) s_hit[k][g] = m;
-                cnt += (uint32_t)__popcll(m);
+        // Four rows per pass: their bounds (pixel box, capsule) are fetched together, so the global-memory latency -- the
+        // whole cost of this phase -- is paid once per pass instead of once per row and array.
+        constexpr int kRowsAtOnce = 4;
+        for (uint32_t k0 = wave; k0 < nrowsteps; k0 += kRowsAtOnce * kWaves) {
+            uint32_t by[kRowsAtOnce], bx_lo[kRowsAtOnce], bx_hi[kRowsAtOnce], cnt[kRowsAtOnce];
+#pragma unroll
+            for (int r = 0; r < kRowsAtOnce; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * kWaves;
+                const bool valid = k < nrowsteps;
+                by[r] = valid ? s_allrows[cursor + k] : 0u;
+                // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
+                bx_lo[r] = valid ? rc_lo[by[r] * P.ntx + tcol] : 1u;
+                bx_hi[r] = valid ? rc_hi[by[r] * P.ntx + tcol] : 0u;
+                cnt[r] = 0u;
             }
-            if (lane == 0) { s_cnt[k] = cnt; s_firstid[k] = 2u * (by * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+            uint32_t g_first = hit_words, g_last = 0;                 // groups of 64 blocks that hold any block of the four ranges
+#pragma unroll
+            for (int r = 0; r < kRowsAtOnce; ++r)
+                if (bx_lo[r] < bx_hi[r]) { g_first = min(g_first, bx_lo[r] >> 6); g_last = max(g_last, ((bx_hi[r] - 1u) >> 6) + 1u); }
+            for (uint32_t g = lane; g < hit_words * kRowsAtOnce; g += 64u) {       // ballots of the groups outside: none
+                const uint32_t k = k0 + (g / hit_words) * kWaves, gg = g % hit_words;
+                if (k < nrowsteps && (gg < g_first || gg >= g_last)) s_hit[k][gg] = 0ull;
+            }
+            for (uint32_t g = g_first; g < g_last; ++g) {
+                const uint32_t bx = g * 64u + lane;
+                PixelBox box[kRowsAtOnce];
+                float4 seg[kRowsAtOnce];
+                float rad[kRowsAtOnce];
+                bool in[kRowsAtOnce];
+#pragma unroll
+                for (int r = 0; r < kRowsAtOnce; ++r) {
+                    in[r] = bx >= bx_lo[r] && bx < bx_hi[r];
+                    box[r] = PixelBox{ 1, 1, 0, 0 }; seg[r] = make_float4(0.f, 0.f, 0.f, 0.f); rad[r] = 0.0f;
+                    if (in[r]) {
+                        const uint32_t bidx = by[r] * P.nb + bx;
+                        box[r] = boxes[bidx]; seg[r] = cap_seg[bidx]; rad[r] = cap_rad[bidx];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < kRowsAtOnce; ++r) {
+                    const uint32_t k = k0 + (uint32_t)r * kWaves;
+                    if (k >= nrowsteps) continue;                                   // uniform
+                    const unsigned long long m = __ballot(in[r] && block_is_candidate(box[r], seg[r], rad[r], T));
+                    if (lane == 0) s_hit[k][g] = m;
+                    cnt[r] += (uint32_t)__popcll(m);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRowsAtOnce; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * kWaves;
+                if (lane == 0 && k < nrowsteps) { s_cnt[k] = cnt[r]; s_firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+            }
         }
         __syncthreads();
         // ---- chunk set-up 2: every wave scans the row counts for itself (two 64-row halves), so all agree on the list offsets
