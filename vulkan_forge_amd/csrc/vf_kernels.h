@@ -711,7 +711,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     VF_PH_INIT
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
@@ -774,14 +775,17 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         if (tid == 0) { s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
         // Four rows per pass: their bounds (pixel box, capsule) are fetched together, so the global-memory latency -- the
         // whole cost of this phase -- is paid once per pass instead of once per row and array.
-        constexpr int kRowsAtOnce = 4;
+#ifndef VF_ROWS_AT_ONCE
+#define VF_ROWS_AT_ONCE 4
+#endif
+        constexpr int kRowsAtOnce = VF_ROWS_AT_ONCE;
         for (uint32_t k0 = wave; k0 < nrowsteps; k0 += kRowsAtOnce * kWaves) {
             uint32_t by[kRowsAtOnce], bx_lo[kRowsAtOnce], bx_hi[kRowsAtOnce], cnt[kRowsAtOnce];
 #pragma unroll
             for (int r = 0; r < kRowsAtOnce; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * kWaves;
                 const bool valid = k < nrowsteps;
-                by[r] = valid ? s_allrows[cursor + k] : 0u;
+                by[r] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]) : 0u;
                 // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
                 bx_lo[r] = valid ? rc_lo[by[r] * P.ntx + tcol] : 1u;
                 bx_hi[r] = valid ? rc_hi[by[r] * P.ntx + tcol] : 0u;
@@ -836,15 +840,19 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
             const uint32_t t0 = __shfl_up(inc0, o), t1 = __shfl_up(inc1, o);
             if (lane >= (uint32_t)o) { inc0 += t0; inc1 += t1; }
         }
-        inc1 += __shfl(inc0, 63);
+        inc1 += (uint32_t)__builtin_amdgcn_readlane((int)inc0, 63);
         const unsigned long long fm0 = __ballot(lane < nrowsteps && inc0 <= kChunk), fm1 = __ballot(lane + 64u < nrowsteps && inc1 <= kChunk);
         // rows are admitted in order: stop at the first one that does not fit (a single row always fits: nb <= 1024 < kChunk)
         const uint32_t nsteps = fm0 != ~0ull ? (uint32_t)__builtin_ctzll(~fm0) : 64u + (fm1 != ~0ull ? (uint32_t)__builtin_ctzll(~fm1) : 64u);
-        const uint32_t nlist = nsteps <= 64u ? __shfl(inc0, (int)nsteps - 1) : __shfl(inc1, (int)nsteps - 65);
+        // wave-uniform values are read with readlane / readfirstlane so that they, and the addresses derived from them, live in
+        // scalar registers: the vector register file is the scarce resource of this kernel
+        const uint32_t nlist = (uint32_t)(nsteps <= 64u ? __builtin_amdgcn_readlane((int)inc0, (int)nsteps - 1)
+                                                         : __builtin_amdgcn_readlane((int)inc1, (int)nsteps - 65));
         // ---- chunk set-up 3: fill the work list from the kept ballots ----
         for (uint32_t k = wave; k < nsteps; k += kWaves) {
-            const uint32_t by = s_allrows[cursor + k];
-            uint32_t pos = k < 64u ? __shfl(inc0 - c0, (int)k) : __shfl(inc1 - c1, (int)k - 64), cnt = 0;
+            const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]);
+            uint32_t pos = (uint32_t)(k < 64u ? __builtin_amdgcn_readlane((int)(inc0 - c0), (int)k) : __builtin_amdgcn_readlane((int)(inc1 - c1), (int)k - 64));
+            uint32_t cnt = 0;
             for (uint32_t g = 0; g < hit_words; ++g) {
                 const unsigned long long m = s_hit[k][g];
                 if ((m >> lane) & 1ull) s_list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
@@ -863,9 +871,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
             if (*v_done) break;
             uint32_t idx = 0;
             if (lane == 0) idx = atomicAdd(&s_next, 1u);
-            idx = __shfl(idx, 0);
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
             if (idx >= nlist) break;
-            const uint32_t entry = s_list[idx];
+            const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
             // late culling against the masks published since the list was built (one column / row per lane)
             bool live;
@@ -954,12 +962,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
             // ---- completion: the DS queue of a wave is FIFO, so this decrement is ordered after the block's paints ----
             uint32_t old = 0;
             if (lane == 0) old = atomicSub(&s_pending[stepidx], 1u);
-            old = __shfl(old, 0);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
             if (old != 1u) { VF_PH(5) continue; }
             // the step is complete: try to advance the frontier (first step that still has unfinished blocks)
             uint32_t got = 0;
             if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
-            got = __shfl(got, 0);
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             if (!got) { VF_PH(5) continue; }                           // somebody else is publishing; masks may lag, never lie
             uint32_t fr = *v_frontier;
             while (fr < nsteps && v_pending[fr] == 0u) ++fr;
@@ -979,7 +987,11 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
         {
             constexpr int kRowsPerWave = kTileH / kWaves;
-            const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane, s_firstid[nsteps - 1], (int32_t)wave * kRowsPerWave,
+            // once per chunk: hide `lane` from the optimiser here, or it computes this unrolled loop's LDS addresses at kernel
+            // entry and keeps them in (in fact: spills them from) vector registers for the whole kernel
+            uint32_t lane_here = lane;
+            asm volatile("" : "+v"(lane_here));
+            const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane_here, s_firstid[nsteps - 1], (int32_t)wave * kRowsPerWave,
                                                  (int32_t)(wave + 1) * kRowsPerWave);
             if (lane == 0) s_part[wave] = nfinal;
         }
