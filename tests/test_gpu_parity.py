@@ -134,6 +134,31 @@ def test_uniform_lanes_drive_the_shader(cabi, oracle, luts, mod):
     assert_parity(rgba, vis, ref_rgba, ref_vis)
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_random_scenes_fuzz(cabi, oracle, luts, seed):
+    """Seeded random frames: odd sizes, eyes above / inside / below / beside the terrain, narrow and wide fields of view,
+    near and far planes that cut the terrain, exaggerated heights (slivers many tiles tall).  Bit-exact visibility, <= 1 LSB."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(1, 400)), int(rng.integers(1, 300))
+    G = int(rng.choice([2, 3, 5, 9, 16, 17, 33, 64, 96]))
+    tex = (int(rng.integers(1, 80)), int(rng.integers(1, 80)))
+    h = (rng.random(tex, dtype=np.float32) - np.float32(0.5)) * np.float32(rng.choice([0.0, 0.2, 1.0, 3.0]))
+    r = float(rng.choice([0.05, 0.6, 2.0, 4.5, 9.0]))
+    th, ph = rng.uniform(0, 2 * math.pi), rng.uniform(-0.6, 1.4)
+    eye = (r * math.cos(th) * math.cos(ph), r * math.sin(ph), r * math.sin(th) * math.cos(ph))
+    target = tuple(float(v) for v in rng.uniform(-0.4, 0.4, 3))
+    fovy = float(rng.choice([20.0, 45.0, 60.0, 120.0, 170.0]))
+    znear = float(rng.choice([1e-3, 0.1, 0.5 * r]))
+    zfar = float(rng.choice([r + 0.3, 100.0, 1e4]))                      # r + 0.3: the far plane cuts through the terrain
+    u = oracle.look_at_uniforms(1, W, H, eye, target, (0.0, 1.0, 0.0), fovy, znear, zfar)
+    u[38] = float(rng.choice([1.0, 1.0, 0.0, 8.0, -2.0]))              # exaggeration
+    u[36] = float(rng.choice([1.0, 1.0, 0.3, 2.5]))                     # spacing
+    cmap = str(rng.choice(["viridis", "magma", "terrain"]))
+    ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts[cmap], nthreads=8)
+    rgba, vis = hip_frame(cabi, u, W, H, G, h, luts[cmap])
+    assert_parity(rgba, vis, ref_rgba, ref_vis)
+
+
 def test_non_finite_heights_do_not_hang_or_fault(cabi, oracle, luts):
     W, H, G = 160, 120, 32
     h = heightmap(3, 32)
@@ -215,6 +240,34 @@ def test_c4_default_camera_full_oracle_parity(c4, oracle, luts):
     rgba = t.read_rgba(); vis = t.read_visibility()
     ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
     assert_parity(rgba, vis, ref_rgba, ref_vis)
+
+
+def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
+    """The frame plan is feedback-driven (last frame's per-tile time orders the work and cuts heavy tiles into column
+    strips).  Jump between two unrelated cameras on one handle: every frame must equal the oracle's, whatever plan the
+    previous camera left behind -- and the strip path must actually have been exercised."""
+    W = H = 1536
+    G = 1536
+    h = heightmap(77, G)
+    cams = [DEFAULT_CAMERA, ((0.3, 0.9, 2.6), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.1, 100.0)]
+    us = [oracle.look_at_uniforms(1, W, H, *c) for c in cams]
+    refs = [oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads())) for u in us]
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h)
+        t.enable_timing(True)
+        strips_seen = 0
+        for k in (0, 0, 0, 1, 0, 1, 1, 1, 0):
+            t.set_uniforms(us[k]); t.render()
+            rgba = t.read_rgba()
+            strips_seen += int((t.item_stats()[:, 0] >> 24).astype(bool).sum())
+            assert np.array_equal(rgba, refs[k][0]), k
+        assert strips_seen > 0
+        t.enable_timing(False)
+        vis = t.read_visibility()
+        assert np.array_equal(vis, refs[0][1])
+    finally:
+        t.close()
 
 
 def test_c5_pose_batch_subset(cabi, oracle, luts):
