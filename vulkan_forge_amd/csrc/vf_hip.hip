@@ -97,7 +97,8 @@ struct vf_terrain {
     float *d_cap_rad = nullptr;          // per block: capsule radius
     uint32_t *d_rc = nullptr;            // per (block row, tile column): [lo | hi) block-column range, 2 * nb * ntx words
     uint2 *d_work = nullptr;             // busy tiles of the frame: (tile, weight), heaviest first
-    uint32_t *d_work_count = nullptr;    // [0] work items, [1] split budget used
+    uint32_t *d_work_count = nullptr;    // [0] work items, [1] split budget used, [3] items the fast tile kernel handed to the complete one
+    uint32_t *d_redo = nullptr;          // those items (indices into d_work)
     uint32_t *d_last_blocks = nullptr;   // feedback: blocks rasterised per tile in the previous frame (+ [ntiles] = mean)
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
@@ -273,7 +274,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
     A((void **)&t->d_work, ((size_t)t->ntx * t->nty + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting
     A((void **)&t->d_last_blocks, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
-    A((void **)&t->d_work_count, 2 * sizeof(uint32_t));
+    A((void **)&t->d_work_count, 4 * sizeof(uint32_t));
+    A((void **)&t->d_redo, ((size_t)t->ntx * t->nty + kSplitBudget) * sizeof(uint32_t));
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
@@ -304,7 +306,7 @@ void vf_terrain_destroy(vf_terrain *t)
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
-                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map };
+                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_redo };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
@@ -514,18 +516,26 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
-        VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, 2 * sizeof(uint32_t), s));
+        VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, 4 * sizeof(uint32_t), s));
         uint32_t *last_mean = t->d_last_blocks + (size_t)t->ntx * t->nty;
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count,
                            t->d_last_blocks, last_mean, t->d_work_count + 1, rc_lo, rc_hi);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count, t->d_last_blocks, t->ntx * t->nty, last_mean);
         if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], s));
-        if (write_vis)
-            hipLaunchKernelGGL(k_tile<true>, dim3(ntiles + kSplitBudget), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, rc_lo, rc_hi, t->d_rgba, t->d_vis, stats, t->d_last_blocks);
-        else
-            hipLaunchKernelGGL(k_tile<false>, dim3(ntiles + kSplitBudget), dim3(kTileThreads), 0, s, P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad,
-                               t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, rc_lo, rc_hi, t->d_rgba, (uint32_t *)nullptr, stats, t->d_last_blocks);
+        // main launch: one workgroup per possible item (tiles + split budget), the fast variant; then a handful of persistent
+        // workgroups of the complete variant for the items that met a clipped or oversized primitive (normally none)
+        uint32_t *redo_count = t->d_work_count + 3;
+        const dim3 all_items(ntiles + kSplitBudget), few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
+#define VF_TILE_ARGS P, A, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, \
+                     rc_lo, rc_hi, t->d_rgba, write_vis ? t->d_vis : (uint32_t *)nullptr, stats, t->d_last_blocks, redo_count, t->d_redo
+        if (write_vis) {
+            hipLaunchKernelGGL((k_tile<true, false>), all_items, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<true, true>), few, threads, 0, s, VF_TILE_ARGS);
+        } else {
+            hipLaunchKernelGGL((k_tile<false, false>), all_items, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<false, true>), few, threads, 0, s, VF_TILE_ARGS);
+        }
+#undef VF_TILE_ARGS
     }
     if (t->timing) { if (!ntiles) VF_HIP_TRY(hipEventRecord(ev[2], s)); VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipGetLastError());

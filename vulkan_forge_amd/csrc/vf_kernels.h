@@ -438,6 +438,9 @@ __device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, floa
 
 __device__ __forceinline__ bool vertex_plain(const GVert &v) { return finite4(v.x, v.y, v.z, v.w) && !(v.z < 0.0f) && !(v.z > v.w); }
 
+// CLIPPED = false: the caller never put a near/far-clipped primitive into the visibility tile (the fast tile kernel), so the
+// clipping code -- calls, stack arrays, scratch memory -- is not compiled in at all.
+template <bool CLIPPED>
 __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk,
                                        const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
@@ -449,7 +452,7 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A
         TriSetup T;
         int64_t e[3];
         if (setup_triangle(v0, v1, v2, P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
-    } else {
+    } else if constexpr (CLIPPED) {
         const GVert v[3] = { v0, v1, v2 };                 // only the clipped path keeps the vertices in memory
         hit = clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr);
     }
@@ -675,7 +678,12 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 #define VF_PH_INIT
 #define VF_PH(p)
 #endif
-template <bool WRITE_VIS>
+// Two variants.  COMPLETE = false is the frame's main launch, one workgroup per planned item: it draws every primitive that
+// needs no clipping and is not oversized -- all of them in ordinary views -- and files an item that met one of the others
+// in `redo`.  COMPLETE = true is a small persistent launch that renders the filed items again, this time with the generic
+// path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
+// of the main kernel leaves it without scratch memory and without a single spilled vector register.
+template <bool WRITE_VIS, bool COMPLETE>
 __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ hblk,
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
@@ -683,9 +691,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                                                        const uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
                                                        const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
-                                                       uint32_t *__restrict__ last_blocks)
+                                                       uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo_count,
+                                                       uint32_t *__restrict__ redo)
 {
-    if (blockIdx.x >= *work_count) return;                 // the launch covers the worst case; only the planned items have work
+    if (!COMPLETE && blockIdx.x >= *work_count) return;    // the launch covers the worst case; only the planned items have work
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -707,17 +716,21 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     __shared__ uint32_t s_rowfin[kTileH * 2];
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
-    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks;
+    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo;
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
-    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     VF_PH_INIT
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
+    uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
+    if (COMPLETE && redo_at >= *redo_count) return;
+next_item:                                                 // (only the COMPLETE variant ever comes back here)
+    const uint32_t item_idx = COMPLETE ? redo[redo_at] : blockIdx.x;
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
-    const uint32_t item = work[blockIdx.x].x;
+    const uint32_t item = work[item_idx].x;
     const uint32_t tile = work_tile(item);
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
@@ -733,7 +746,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     for (int k = tid; k < kTileW * 2; k += kTileThreads) s_colfin[k] = 0u;
     for (int k = tid; k < kTileH * 2; k += kTileThreads) s_rowfin[k] = 0u;
     if (tid < 16) s_rows[tid] = 0ull;
-    if (tid == 0) { s_done = 0; s_blocks = 0; }
+    if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
     __syncthreads();
     // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
     for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
@@ -919,7 +932,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
                         const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
                         k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
                         k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
-                        if (k0 == 2 || k1 == 2) {                                            // rare: clipped / oversized
+                        if (!COMPLETE && (k0 == 2 || k1 == 2)) s_redo = 1u;                  // rare: clipped / oversized -> the COMPLETE launch
+                        if constexpr (COMPLETE) if (k0 == 2 || k1 == 2) {
                             const uint32_t prim = 2u * (j * P.nm1 + i);
                             GVert gv[3];                                               // in memory only on this rare path
                             if (k0 == 2) { load_prim(P, A, hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
@@ -1006,8 +1020,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     VF_PH(6)
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
-        stats[4 + 4 * blockIdx.x] = item; stats[5 + 4 * blockIdx.x] = s_blocks;
-        stats[6 + 4 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
+        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_blocks;
+        stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
         const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-        rgba[o] = id ? shade_pixel(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
+        rgba[o] = id ? shade_pixel<COMPLETE>(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
 #ifdef VF_PHASE_PROF
@@ -1037,7 +1051,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
-        if (stats) stats[7 + 4 * blockIdx.x] = ticks;        // raster + fragment phase
+        if (stats) stats[7 + 4 * item_idx] = ticks;        // raster + fragment phase
+        if (!COMPLETE && s_redo) redo[atomicAdd(redo_count, 1u)] = item_idx;   // this item met a primitive the fast path skips
+    }
+    if constexpr (COMPLETE) {
+        redo_at += gridDim.x;
+        __syncthreads();                                   // the next item re-initialises the tile state
+        if (redo_at < *redo_count) goto next_item;
     }
 }
 
