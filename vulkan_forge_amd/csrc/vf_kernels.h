@@ -301,24 +301,24 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
 }
 
 // primitive -> clip-space vertices with varyings (used by the clipped path and the fragment stage)
-__device__ __forceinline__ GVert load_vertex(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t i, uint32_t j)
+__device__ __forceinline__ GVert load_vertex(const FrameParams &P, const float *__restrict__ hblk, uint32_t i, uint32_t j)
 {
-    const float x = A.xs[i], z = A.xs[j];
+    const float x = grid_coord(P, i), z = grid_coord(P, j);
     const ClipVert c = vertex_shader(P, x, z, cached_height(hblk, P.nb, i, j));
     GVert v;
     v.x = c.x; v.y = c.y; v.z = c.z; v.w = c.w;
     v.a[0] = c.h; v.a[1] = x; v.a[2] = z;                  // varyings: height, xz (terrain.wgsl:63-64)
     return v;
 }
-__device__ __forceinline__ void load_prim(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk, uint32_t prim,
+__device__ __forceinline__ void load_prim(const FrameParams &P, const float *__restrict__ hblk, uint32_t prim,
                                           GVert &v0, GVert &v1, GVert &v2)
 {
     // indices [a,c,b, b,c,d] (src/terrain/mod.rs:578-582): even = (a, c, b), odd = (b, c, d)
     const uint32_t cell = prim >> 1, odd = prim & 1u;
     const uint32_t j = cell / P.nm1, i = cell - j * P.nm1;
-    v0 = load_vertex(P, A, hblk, odd ? i + 1 : i, j);
-    v1 = load_vertex(P, A, hblk, i, j + 1);
-    v2 = load_vertex(P, A, hblk, i + 1, odd ? j + 1 : j);
+    v0 = load_vertex(P, hblk, odd ? i + 1 : i, j);
+    v1 = load_vertex(P, hblk, i, j + 1);
+    v2 = load_vertex(P, hblk, i + 1, odd ? j + 1 : j);
 }
 
 // clipped or oversized primitives: clip, fan, and scan each piece's bbox inside the tile with the
@@ -441,11 +441,11 @@ __device__ __forceinline__ bool vertex_plain(const GVert &v) { return finite4(v.
 // CLIPPED = false: the caller never put a near/far-clipped primitive into the visibility tile (the fast tile kernel), so the
 // clipping code -- calls, stack arrays, scratch memory -- is not compiled in at all.
 template <bool CLIPPED>
-__device__ inline uint32_t shade_pixel(const FrameParams &P, const AxisTables &A, const float *__restrict__ hblk,
+__device__ inline uint32_t shade_pixel(const FrameParams &P, const float *__restrict__ hblk,
                                        const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
     GVert v0, v1, v2;
-    load_prim(P, A, hblk, prim, v0, v1, v2);
+    load_prim(P, hblk, prim, v0, v1, v2);
     float attr[3] = { 0.f, 0.f, 0.f };
     bool hit = false;
     if (vertex_plain(v0) && vertex_plain(v1) && vertex_plain(v2)) {
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
 // of the main kernel leaves it without scratch memory and without a single spilled vector register.
 template <bool WRITE_VIS, bool COMPLETE>
-__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, AxisTables A, const float *__restrict__ hblk,
+__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const float *__restrict__ hblk,
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
@@ -936,8 +936,8 @@ next_item:                                                 // (only the COMPLETE
                         if constexpr (COMPLETE) if (k0 == 2 || k1 == 2) {
                             const uint32_t prim = 2u * (j * P.nm1 + i);
                             GVert gv[3];                                               // in memory only on this rare path
-                            if (k0 == 2) { load_prim(P, A, hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
-                            if (k1 == 2) { load_prim(P, A, hblk, prim + 1u, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                            if (k0 == 2) { load_prim(P, hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                            if (k1 == 2) { load_prim(P, hblk, prim + 1u, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
                         }
                     }
                     const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
@@ -1032,7 +1032,7 @@ next_item:                                                 // (only the COMPLETE
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
         const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-        rgba[o] = id ? shade_pixel<COMPLETE>(P, A, hblk, S, id - 1u, px, py) : P.clear_rgba;
+        rgba[o] = id ? shade_pixel<COMPLETE>(P, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
 #ifdef VF_PHASE_PROF
