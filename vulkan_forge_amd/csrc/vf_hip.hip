@@ -525,7 +525,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         // main launch: one workgroup per possible item (tiles + split budget), the fast variant; then a handful of persistent
         // workgroups of the complete variant for the items that met a clipped or oversized primitive (normally none)
         uint32_t *redo_count = t->d_work_count + 3;
-        const dim3 all_items(ntiles + kSplitBudget), few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
+        const dim3 all_items(VF_PERSISTENT ? std::min<uint32_t>((uint32_t)t->ctx->prop.multiProcessorCount, ntiles + kSplitBudget) : ntiles + kSplitBudget), few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
 #define VF_TILE_ARGS P, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, \
                      rc_lo, rc_hi, t->d_rgba, write_vis ? t->d_vis : (uint32_t *)nullptr, stats, t->d_last_blocks, redo_count, t->d_redo
         if (write_vis) {

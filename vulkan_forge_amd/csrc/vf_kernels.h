@@ -22,6 +22,9 @@
 // block row r: after a block row has been rasterised, covered pixels are final.
 #pragma once
 #include "vf_device.h"
+#ifndef VF_PERSISTENT
+#define VF_PERSISTENT 1   // tile kernel: one persistent workgroup per CU pulls items (0: one workgroup per possible item)
+#endif
 
 namespace vf {
 
@@ -688,13 +691,15 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
                                                        const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
-                                                       const uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
+                                                       const uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                                        const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
                                                        uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo_count,
                                                        uint32_t *__restrict__ redo)
 {
+#if !VF_PERSISTENT
     if (!COMPLETE && blockIdx.x >= *work_count) return;    // the launch covers the worst case; only the planned items have work
+#endif
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     __shared__ uint32_t s_rowfin[kTileH * 2];
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
-    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo;
+    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
@@ -726,8 +731,21 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;
+#if VF_PERSISTENT
+    const uint32_t nwork = *work_count;
+    uint32_t pulled = 0;
+    if (!COMPLETE) {
+        if (tid == 0) s_item = atomicAdd(work_count + 2, 1u);
+        __syncthreads();
+        pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (pulled >= nwork) return;
+    }
+next_item:
+    const uint32_t item_idx = COMPLETE ? redo[redo_at] : pulled;
+#else
 next_item:                                                 // (only the COMPLETE variant ever comes back here)
     const uint32_t item_idx = COMPLETE ? redo[redo_at] : blockIdx.x;
+#endif
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[item_idx].x;
@@ -1059,6 +1077,15 @@ next_item:                                                 // (only the COMPLETE
         __syncthreads();                                   // the next item re-initialises the tile state
         if (redo_at < *redo_count) goto next_item;
     }
+#if VF_PERSISTENT
+    else {
+        __syncthreads();
+        if (tid == 0) s_item = atomicAdd(work_count + 2, 1u);
+        __syncthreads();
+        pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (pulled < nwork) goto next_item;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
