@@ -729,6 +729,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     VF_PH_INIT
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
+    for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
+    for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;
 #if VF_PERSISTENT
@@ -759,8 +761,6 @@ next_item:                                                 // (only the COMPLETE
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
-    for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
-    for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
     for (int k = tid; k < kTileW * 2; k += kTileThreads) s_colfin[k] = 0u;
     for (int k = tid; k < kTileH * 2; k += kTileThreads) s_rowfin[k] = 0u;
     if (tid < 16) s_rows[tid] = 0ull;
