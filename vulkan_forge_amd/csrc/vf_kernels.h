@@ -1064,6 +1064,8 @@ next_item:                                                 // (only the COMPLETE
         }
         atomicAdd(&ph[11], (unsigned long long)RC.lines); atomicAdd(&ph[12], (unsigned long long)RC.solved);
         atomicAdd(&ph[13], (unsigned long long)RC.painted); atomicAdd(&ph[14], (unsigned long long)RC.paint_lines);
+        for (int p = 0; p < 8; ++p) ph_acc[p] = 0;           // flushed per item: a persistent workgroup comes here once per item
+        RC = RasterCounts{0, 0, 0, 0, 0, 0}; rc_nsurv = rc_iters = rc_live = rc_empty = 0;
     }
 #endif
     if (tid == 0) {
