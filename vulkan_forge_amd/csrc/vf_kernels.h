@@ -608,8 +608,20 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
         }
         return;
     }
-    // background tile: clear colour (src/terrain/mod.rs:421), one row segment per wave-instruction
+    // background tile: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
+    // (this pass is pure HBM write bandwidth: 49 MiB of the C4 default frame); edge tiles and odd widths go pixel by pixel.
     const int32_t w = px_hi - px_lo + 1, h = py_hi - py_lo + 1;
+    if (w == kTileW && (tp.out_stride & 3u) == 0u && (tp.out_base & 3u) == 0u && (reinterpret_cast<uintptr_t>(rgba) & 15u) == 0u &&
+        (!vis_out || (reinterpret_cast<uintptr_t>(vis_out) & 15u) == 0u)) {
+        const uint4 c4 = make_uint4(P.clear_rgba, P.clear_rgba, P.clear_rgba, P.clear_rgba), z4 = make_uint4(0u, 0u, 0u, 0u);
+        for (int32_t k = threadIdx.x; k < (kTileW / 4) * h; k += 256) {
+            const int32_t ly = k / (kTileW / 4), q = k - ly * (kTileW / 4);
+            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + 4u * (uint32_t)q;
+            *reinterpret_cast<uint4 *>(rgba + o) = c4;
+            if (vis_out) *reinterpret_cast<uint4 *>(vis_out + o) = z4;
+        }
+        return;
+    }
     for (int32_t k = threadIdx.x; k < w * h; k += 256) {
         const int32_t ly = k / w, lx = k - ly * w;
         const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)lx;
