@@ -229,7 +229,7 @@ def main():
     kernel_s = tm["tile_ms"] * 1e-3                               # `share` = this rank's share of the frame's pixels
     rank_bytes = int(4 * G * G + 4 * W * H * share + 1024)
     achieved = rank_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic = None
+    traffic, sq = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -237,12 +237,16 @@ def main():
             key = f"{W}x{H}_g{G}_{args.camera}_n{world}"
             if key in pm:
                 traffic = pm[key]["hbm_bytes_per_launch"]
+                sq = pm[key].get("sq")
         except Exception:  # noqa: BLE001
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": rank_bytes, "kernel_ms": tm["tile_ms"],
                 "other_kernels_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
+    if sq:   # the path has no contraction and is not HBM-bound: what it IS bound by, from the committed SQ counter passes
+        roofline["valu_busy_frac"] = sq["valu_busy_frac"]
+        roofline["active_lanes_per_valu_inst"] = sq["active_lanes_per_valu_inst"]
 
     # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
     cpu = None
