@@ -47,6 +47,8 @@ entry = {
 }
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 data = json.load(open(out)) if os.path.exists(out) else {}
+if key in data and "sq" in data[key]:
+    entry["sq"] = data[key]["sq"]          # SQ utilisation block is maintained separately (r01_j_sq_counters.txt)
 data[key] = entry
 json.dump(data, open(out, "w"), indent=1)
 print(key, json.dumps(entry))
