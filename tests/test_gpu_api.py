@@ -189,3 +189,46 @@ def test_cli_tools_on_the_gpu(tmp_path):
     assert device_diagnostics.main(["--json", str(tmp_path / "diag.json")]) == 0
     diag = json.loads((tmp_path / "diag.json").read_text())
     assert diag["backends"]["hip"]["adapters"] and diag["errors"] == []
+
+
+# ---- C-ABI contract: status codes + vf_last_error, never a crash -----------------------------------------------------
+def test_cabi_misuse_reports_errors(luts):
+    import ctypes as C
+    from vulkan_forge_amd import cabi
+    lib = cabi.load()
+    ctx = C.c_void_p()
+    assert lib.vf_ctx_create(0, C.byref(ctx)) == cabi.VF_OK
+    t = C.c_void_p()
+    lut = np.ascontiguousarray(luts["viridis"], np.uint8).reshape(1024)
+    for w, h, g in ((0, 10, 8), (10, 0, 8), (20000, 10, 8), (10, 10, 9000)):      # (grid < 2 is raised to 2 like src/terrain/mod.rs:260)
+        assert lib.vf_terrain_create(ctx, w, h, g, lut.ctypes.data, 1, C.byref(t)) == cabi.VF_ERR_INVALID, (w, h, g)
+        assert lib.vf_last_error()
+    assert lib.vf_terrain_create(ctx, 64, 48, 8, None, 1, C.byref(t)) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_create(None, 64, 48, 8, lut.ctypes.data, 1, C.byref(t)) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_create(ctx, 64, 48, 8, lut.ctypes.data, 1, C.byref(t)) == cabi.VF_OK
+    buf = np.zeros((48, 64, 4), np.uint8)
+    assert lib.vf_terrain_render(t, None) == cabi.VF_ERR_INVALID                      # uniforms not set
+    assert b"uniforms" in lib.vf_last_error()
+    assert lib.vf_terrain_read_rgba(t, buf.ctypes.data, 0, 48) == cabi.VF_ERR_INVALID  # nothing rendered
+    u = np.zeros(44, np.float32); u[0] = u[5] = u[10] = u[15] = 1.0; u[16] = u[21] = u[26] = u[31] = 1.0
+    assert lib.vf_terrain_set_uniforms(t, u.ctypes.data) == cabi.VF_OK
+    assert lib.vf_terrain_set_uniforms(t, None) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_set_height(t, None, 4, 4) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_set_height(t, buf.ctypes.data, 0, 4) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_set_shard(t, 2, 2, 64) == cabi.VF_ERR_INVALID               # rank >= nranks
+    assert lib.vf_terrain_set_shard(t, 0, 2, 48) == cabi.VF_ERR_INVALID               # band_h not a power of two
+    assert lib.vf_terrain_set_shard(t, 0, 2, 32) == cabi.VF_ERR_INVALID               # band_h below the tile height
+    assert lib.vf_terrain_set_tile_shard(t, 3, 3, 1) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_set_shade_mode(t, 7) == cabi.VF_ERR_INVALID
+    assert lib.vf_terrain_render(t, None) == cabi.VF_OK                               # identity matrices: still a valid frame
+    assert lib.vf_terrain_read_rgba(t, buf.ctypes.data, 40, 9) == cabi.VF_ERR_INVALID  # rows outside the frame
+    assert lib.vf_terrain_read_rgba(t, buf.ctypes.data, 0, 48) == cabi.VF_OK
+    n = C.c_uint32()
+    assert lib.vf_tile_layout(0, 10, 0, 1, 1, None, 0, C.byref(n)) == cabi.VF_ERR_INVALID
+    assert lib.vf_tile_layout(100, 100, 0, 1, 1, None, 0, None) == cabi.VF_ERR_INVALID
+    stats = np.zeros(64, np.uint32)
+    assert lib.vf_terrain_debug_item_stats(t, stats.ctypes.data, 16, C.byref(n)) == cabi.VF_ERR_INVALID   # timing not enabled
+    assert lib.vf_terrain_debug_phase_cycles(t, stats.ctypes.data, 8) == cabi.VF_ERR_INVALID              # not a profiling build
+    lib.vf_terrain_destroy(t); lib.vf_terrain_destroy(None)
+    lib.vf_ctx_destroy(ctx); lib.vf_ctx_destroy(None)
+    assert lib.vf_ctx_create(99, C.byref(ctx)) != cabi.VF_OK                          # no such device
