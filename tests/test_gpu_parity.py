@@ -270,6 +270,29 @@ def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
         t.close()
 
 
+def test_maximum_grid_8192(cabi, oracle, luts):
+    """Largest grid the C-ABI accepts (8192: 1024 x 1024 blocks, the limit of the tile kernel's 10-bit block indices):
+    oracle parity at 2048 x 1536, and interleaved-tile shards that reassemble to the same frame."""
+    W, H, G = 2048, 1536, 8192
+    h = heightmap(1, G)
+    u = oracle.default_uniforms(1, W, H)
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h); t.set_uniforms(u)
+        t.render(); a = t.read_rgba()
+        ref, _ = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()), want_vis=False)
+        assert np.array_equal(a, ref)
+        out = np.zeros_like(a)
+        for r in range(3):
+            t.set_tile_shard(r, 3, 5); t.render()
+            tiles = t.read_tiles()
+            for k, (tx, ty) in enumerate(cabi.tile_layout(W, H, r, 3, 5, lib=t.lib)):
+                out[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = tiles[k]
+        assert np.array_equal(out, a)
+    finally:
+        t.close()
+
+
 def test_c5_pose_batch_subset(cabi, oracle, luts):
     """BASELINE config 5: 64 look-ats on the default camera's orbit over one terrain (SURVEY.md 8(d) C5);
     8 of the 64 poses at a quarter-size frame against the oracle, one terrain object reused for all poses."""
