@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
         }
     }
     __syncthreads();
-    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { rc_lo[by * P.ntx + tc] = s_lo[tc]; rc_hi[by * P.ntx + tc] = s_hi[tc]; }
+    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { rc_lo[tc * P.nb + by] = s_lo[tc]; rc_hi[tc * P.nb + by] = s_hi[tc]; }   // [tile column][block row]: a tile reads its column's rows contiguously
     if (threadIdx.x == 0) {
         PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     const uint32_t tcol = tp.tx;
     for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
         const PixelBox rr = row_boxes[r];
-        hits += (rc_lo[r * P.ntx + tcol] < rc_hi[r * P.ntx + tcol] && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
+        hits += (rc_lo[tcol * P.nb + r] < rc_hi[tcol * P.nb + r] && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
     }
     for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
     if ((threadIdx.x & 63u) == 0 && hits) atomicAdd(&s_hits, hits);
@@ -784,7 +784,7 @@ next_item:                                                 // (only the COMPLETE
         bool hit = false;
         if (r < P.nb) {
             const PixelBox rr = row_boxes[r];
-            hit = rc_lo[r * P.ntx + tcol] < rc_hi[r * P.ntx + tcol] && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi &&
+            hit = rc_lo[tcol * P.nb + r] < rc_hi[tcol * P.nb + r] && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi &&
                   rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
         }
         const unsigned long long m = __ballot(hit);
@@ -830,8 +830,8 @@ next_item:                                                 // (only the COMPLETE
                 const bool valid = k < nrowsteps;
                 by[r] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]) : 0u;
                 // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
-                bx_lo[r] = valid ? rc_lo[by[r] * P.ntx + tcol] : 1u;
-                bx_hi[r] = valid ? rc_hi[by[r] * P.ntx + tcol] : 0u;
+                bx_lo[r] = valid ? rc_lo[tcol * P.nb + by[r]] : 1u;
+                bx_hi[r] = valid ? rc_hi[tcol * P.nb + by[r]] : 0u;
                 cnt[r] = 0u;
             }
             uint32_t g_first = hit_words, g_last = 0;                 // groups of 64 blocks that hold any block of the four ranges
