@@ -511,7 +511,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     }
     const size_t rc_n = (size_t)t->nb * t->ntx;
     uint32_t *rc_lo = t->d_rc, *rc_hi = t->d_rc + rc_n;
-    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(256), 0, s, P, A, t->d_bounds, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, rc_lo, rc_hi);
+    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(t->nb > 256 ? 512 : 256), 0, s, P, t->d_bounds, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, rc_lo, rc_hi);
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     if (ntiles) {

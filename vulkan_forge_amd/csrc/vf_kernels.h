@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void k_height_blocks(uint32_t n, uint32_t nb, u
 // the projected bottom / top faces, so the whole block lies within `rad` of the segment joining the two face centres
 // (rad = largest centre-to-corner distance + 1 px).  For oblique views the streak a block sweeps is long and thin
 // and the capsule rejects most of the tiles its bounding box crosses.
-__global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A, const float2 *__restrict__ bounds,
+__global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2 *__restrict__ bounds,
                                                      PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes,
                                                      float4 *__restrict__ cap_seg, float *__restrict__ cap_rad,
                                                      uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi)
@@ -96,13 +96,14 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
     __shared__ uint32_t s_lo[kMaxTileCols], s_hi[kMaxTileCols];   // this block row's [first, last+1) block per tile column
     const uint32_t by = blockIdx.x;
     if (threadIdx.x == 0) { s_rr[0] = 0x7FFF; s_rr[1] = 0x7FFF; s_rr[2] = -1; s_rr[3] = -1; }
-    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { s_lo[tc] = 0xFFFFFFFFu; s_hi[tc] = 0u; }
+    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += blockDim.x) { s_lo[tc] = 0xFFFFFFFFu; s_hi[tc] = 0u; }
     __syncthreads();
-    for (uint32_t bx = threadIdx.x; bx < P.nb; bx += 256) {
+    for (uint32_t bx = threadIdx.x; bx < P.nb; bx += blockDim.x) {
         const uint32_t b = by * P.nb + bx;
         const float2 hb = bounds[b];
         const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
         const uint32_t i1 = min(i0 + kBlockCells, P.n - 1), j1 = min(j0 + kBlockCells, P.n - 1);
+        const float x0 = grid_coord(P, i0), x1 = grid_coord(P, i1), z0 = grid_coord(P, j0), z1 = grid_coord(P, j1);   // = AxisTables::xs, bit for bit
         float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         float cxs[8], cys[8];
         int regular = 0, out_near = 0, out_far = 0;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             cxs[c] = 0.0f; cys[c] = 0.0f;
-            float x = A.xs[(c & 1) ? i1 : i0], z = A.xs[(c & 2) ? j1 : j0], h = (c & 4) ? hb.y : hb.x;
+            float x = (c & 1) ? x1 : x0, z = (c & 2) ? z1 : z0, h = (c & 4) ? hb.y : hb.x;
             float vp[4], cp[4];
             mat_vec(P.view, x * P.spacing, h * P.exag, z * P.spacing, 1.0f, vp);
             mat_vec(P.proj, vp[0], vp[1], vp[2], vp[3], cp);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_block_boxes(FrameParams P, AxisTables A
         }
     }
     __syncthreads();
-    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += 256) { rc_lo[tc * P.nb + by] = s_lo[tc]; rc_hi[tc * P.nb + by] = s_hi[tc]; }   // [tile column][block row]: a tile reads its column's rows contiguously
+    for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += blockDim.x) { rc_lo[tc * P.nb + by] = s_lo[tc]; rc_hi[tc * P.nb + by] = s_hi[tc]; }   // [tile column][block row]: a tile reads its column's rows contiguously
     if (threadIdx.x == 0) {
         PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
