@@ -4,7 +4,8 @@
   metric   Mpix/s terrain shade: W*H*frames / wall time, RGBA8 complete in HBM (rank 0 holds the gathered frame)
   workload C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
            (np.random.default_rng(20250816).random(float32)*0.5-0.25), default camera eye (3,2,3), viridis.
-           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort + k_tile (+ gather to rank 0 + stitch when N > 1).
+           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort (on the handle's side stream: they only touch plan state and
+           overlap the previous frame's tile kernel) + k_clear + k_tile (+ gather to rank 0 + stitch when N > 1).
   N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): screen-tile split -- 64x64 tile (tx, ty)
            belongs to rank (tx + skew*ty) % N; every rank renders only its tiles into a tile-major slab, the slabs go to
            rank 0 point-to-point over xGMI (vulkan_forge_amd/dist.py::TileExchange) and vf_stitch_tiles_device writes the
@@ -161,8 +162,8 @@ def main():
     if ex is not None:
         ex.pending_frame = [False] * depth
 
-    SETTLE = 6   # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
-                 # splitting) and needs a few frames of a new camera to converge; results never depend on it
+    SETTLE = 16  # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
+                 # splitting; two frames old, because frames overlap) and needs a few frames of a new camera to converge; results never depend on it
 
     def timed(camera, steps, warmup):
         t.set_uniforms(camera_uniforms(camera, W, H))
@@ -240,10 +241,10 @@ def main():
                 sq = pm[key].get("sq")
         except Exception:  # noqa: BLE001
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_clear + k_tile (the kernels on the caller's stream: they produce the frame)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": rank_bytes, "kernel_ms": tm["tile_ms"],
-                "other_kernels_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
+                "plan_on_side_stream_elapsed_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
     if sq:   # the path has no contraction and is not HBM-bound: what it IS bound by, from the committed SQ counter passes
         roofline["valu_busy_frac"] = sq["valu_busy_frac"]
         roofline["active_lanes_per_valu_inst"] = sq["active_lanes_per_valu_inst"]

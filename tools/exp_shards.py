@@ -17,7 +17,7 @@ for cam in ("default", "fill"):
             for r in range(n):
                 if band: t.set_shard(r, n, band)
                 else: t.set_tile_shard(r, n, {1: 1, 2: 1, 4: 3, 8: 3}[n])
-                for _ in range(6): t.render()
+                for _ in range(30): t.render()
                 t.enable_timing(True); t.render(); t.render(); tm = t.timings(); t.enable_timing(False)
                 times.append(tm["total_ms"])
             print(f"{cam:8s} band={band:4d} N={n}: per-rank ms max={max(times):.3f} min={min(times):.3f} sum={sum(times):.3f}  -> speedup vs N=1 (compute only) = {base/max(times) if n>1 else 1.0:.2f}" if n > 1 else f"{cam:8s} band={band:4d} N=1: {times[0]:.3f} ms", flush=True)

@@ -91,15 +91,23 @@ struct vf_terrain {
     bool bounds_dirty = true;
     float2 *d_bounds = nullptr;          // per block: min/max displaced height
     float *d_hblk = nullptr;             // displaced-height cache: 81 floats per block
-    PixelBox *d_ranges = nullptr;       // per block: tile rectangle (per frame)
-    PixelBox *d_row_ranges = nullptr;   // per block row
-    float4 *d_cap_seg = nullptr;         // per block: capsule axis (screen space)
-    float *d_cap_rad = nullptr;          // per block: capsule radius
-    uint32_t *d_rc = nullptr;            // per (block row, tile column): [lo | hi) block-column range, 2 * nb * ntx words
-    uint2 *d_work = nullptr;             // busy tiles of the frame: (tile, weight), heaviest first
-    uint32_t *d_work_count = nullptr;    // [0] work items, [1] split budget used, [3] items the fast tile kernel handed to the complete one
-    uint32_t *d_redo = nullptr;          // those items (indices into d_work)
-    uint32_t *d_last_blocks = nullptr;   // feedback: blocks rasterised per tile in the previous frame (+ [ntiles] = mean)
+    // Per-frame plan state, twice: frame f uses set f & 1.  The plan kernels of a frame run on `side` and touch nothing else,
+    // so they overlap the previous frame's tile kernel (which still reads the other set) instead of waiting for it.
+    struct PlanState {
+        PixelBox *ranges = nullptr;      // per block: tile rectangle
+        PixelBox *row_ranges = nullptr;  // per block row
+        float4 *cap_seg = nullptr;       // per block: capsule axis (screen space)
+        float *cap_rad = nullptr;        // per block: capsule radius
+        uint32_t *rc = nullptr;          // per (tile column, block row): [lo | hi) block-column range, 2 * nb * ntx words
+        uint2 *work = nullptr;           // busy tiles of the frame: (item, weight), heaviest first
+        uint32_t *work_count = nullptr;  // [0] work items, [1] split budget used, [2] queue head, [3] items handed to the complete tile kernel
+        uint32_t *redo = nullptr;        // those items (indices into work)
+        uint32_t *background = nullptr;  // per local tile: 1 = no block row reaches it
+        uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later (+ [ntiles] = split quantum)
+        hipEvent_t planned = nullptr, drawn = nullptr;
+    } ps[2];
+    hipStream_t side = nullptr;
+    uint32_t frame_no = 0;
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint8_t *d_png = nullptr, *h_png = nullptr;   // PNG scanlines of the last frame: device, pinned host
@@ -115,7 +123,8 @@ struct vf_terrain {
     // timing: a ring of (start, after block boxes, after plan, after tile) events, one set per rendered frame
     static constexpr int kTimingRing = 64;
     bool timing = false;
-    hipEvent_t ev[kTimingRing][4] = {};
+    hipEvent_t ev[kTimingRing][5] = {};   // plan start, after block boxes, after plan (side stream); after tile, before clear (caller's stream)
+    hipEvent_t entry = nullptr;          // caller's stream at render entry (orders a height-cache rebuild after the caller's work)
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
     bool rendered = false;
@@ -267,15 +276,23 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_height_own, sizeof(float));
     A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
     A((void **)&t->d_hblk, (size_t)t->nblocks * kBlockStride * sizeof(float));
-    A((void **)&t->d_ranges, t->nblocks * sizeof(PixelBox));
-    A((void **)&t->d_row_ranges, t->nb * sizeof(PixelBox));
-    A((void **)&t->d_cap_seg, t->nblocks * sizeof(float4));
-    A((void **)&t->d_cap_rad, t->nblocks * sizeof(float));
-    A((void **)&t->d_rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
-    A((void **)&t->d_work, ((size_t)t->ntx * t->nty + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting
-    A((void **)&t->d_last_blocks, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
-    A((void **)&t->d_work_count, 4 * sizeof(uint32_t));
-    A((void **)&t->d_redo, ((size_t)t->ntx * t->nty + kSplitBudget) * sizeof(uint32_t));
+    const size_t all_tiles = (size_t)t->ntx * t->nty;
+    for (auto &S : t->ps) {
+        A((void **)&S.ranges, t->nblocks * sizeof(PixelBox));
+        A((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
+        A((void **)&S.cap_seg, t->nblocks * sizeof(float4));
+        A((void **)&S.cap_rad, t->nblocks * sizeof(float));
+        A((void **)&S.rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
+        A((void **)&S.work, (all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting
+        A((void **)&S.feedback, (all_tiles + 1) * sizeof(uint32_t));
+        A((void **)&S.work_count, 4 * sizeof(uint32_t));
+        A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
+        A((void **)&S.background, all_tiles * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles + 1) * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
+    }
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
@@ -283,9 +300,9 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t));
     for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
-        for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
+        for (int k = 0; k < 5 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -305,14 +322,21 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_ranges,
-                     t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_rc, t->d_work, t->d_work_count, t->d_last_blocks, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_redo };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &S : t->ps) {
+        void *sp[] = { S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
+        for (void *p : sp) if (p) (void)hipFree(p);
+        if (S.planned) (void)hipEventDestroy(S.planned);
+        if (S.drawn) (void)hipEventDestroy(S.drawn);
+    }
+    if (t->side) (void)hipStreamDestroy(t->side);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
     if (t->d_png) (void)hipFree(t->d_png);
     if (t->h_png) (void)hipHostFree(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
+    if (t->entry) (void)hipEventDestroy(t->entry);
     delete t;
 }
 
@@ -385,7 +409,8 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->local_tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
     t->rendered = false;
     // tile numbering changed: forget the scheduling feedback of the previous layout
-    VF_HIP_TRY(hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    for (auto &S : t->ps) VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
     return VF_OK;
 }
 
@@ -422,7 +447,8 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->rank = rank; t->nranks = nranks; t->skew = skew;
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
     t->rendered = false;
-    VF_HIP_TRY(hipMemset(t->d_last_blocks, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    for (auto &S : t->ps) VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
     return VF_OK;
 }
 
@@ -498,46 +524,61 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     FrameParams P;
     build_params(t, P);
     AxisTables A = axis(t);
+    const uint32_t ntiles = t->local_tiles;
+    vf_terrain::PlanState &S = t->ps[t->frame_no++ & 1u];
+    hipStream_t side = t->side;
+    hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
+    // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
+    VF_HIP_TRY(hipStreamWaitEvent(side, S.drawn, 0));
     if (t->bounds_dirty) {
-        hipLaunchKernelGGL(k_height_blocks, dim3(t->nblocks), dim3(64), 0, s, t->n, t->nb, t->tw, A, t->d_height, t->d_hblk, t->d_bounds);
+        // the height texture may have been produced by work queued on the caller's stream: order the cache rebuild after it
+        VF_HIP_TRY(hipEventRecord(t->entry, s));
+        VF_HIP_TRY(hipStreamWaitEvent(side, t->entry, 0));
+        hipLaunchKernelGGL(k_height_blocks, dim3(t->nblocks), dim3(64), 0, side, t->n, t->nb, t->tw, A, t->d_height, t->d_hblk, t->d_bounds);
         VF_HIP_TRY(hipGetLastError());
         t->bounds_dirty = false;
     }
-    const uint32_t ntiles = t->local_tiles;
-    hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
-    if (t->timing) {
-        VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t), s));
-        VF_HIP_TRY(hipEventRecord(ev[0], s));
-    }
+    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[0], side));
     const size_t rc_n = (size_t)t->nb * t->ntx;
-    uint32_t *rc_lo = t->d_rc, *rc_hi = t->d_rc + rc_n;
-    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(t->nb > 256 ? 512 : 256), 0, s, P, t->d_bounds, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, rc_lo, rc_hi);
-    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], s));
+    uint32_t *rc_lo = S.rc, *rc_hi = S.rc + rc_n;
+    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi);
+    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
+    if (ntiles) {
+        VF_HIP_TRY(hipMemsetAsync(S.work_count, 0, 4 * sizeof(uint32_t), side));
+        uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
+        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
+                           S.feedback, quantum, S.work_count + 1, rc_lo, rc_hi);
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
+    }
+    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
+    VF_HIP_TRY(hipEventRecord(S.planned, side));
+    // ---- draw, on the caller's stream: everything that touches the output buffers ----
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
+    if (t->timing) VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t), s));
+    VF_HIP_TRY(hipStreamWaitEvent(s, S.planned, 0));
+    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
-        VF_HIP_TRY(hipMemsetAsync(t->d_work_count, 0, 4 * sizeof(uint32_t), s));
-        uint32_t *last_mean = t->d_last_blocks + (size_t)t->ntx * t->nty;
-        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, s, P, t->d_row_ranges, t->d_rgba, vis, t->d_work, t->d_work_count,
-                           t->d_last_blocks, last_mean, t->d_work_count + 1, rc_lo, rc_hi);
-        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, s, t->d_work, t->d_work_count, t->d_last_blocks, t->ntx * t->nty, last_mean);
-        if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], s));
-        // main launch: one workgroup per possible item (tiles + split budget), the fast variant; then a handful of persistent
-        // workgroups of the complete variant for the items that met a clipped or oversized primitive (normally none)
-        uint32_t *redo_count = t->d_work_count + 3;
-        const dim3 all_items(VF_PERSISTENT ? std::min<uint32_t>((uint32_t)t->ctx->prop.multiProcessorCount, ntiles + kSplitBudget) : ntiles + kSplitBudget), few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
-#define VF_TILE_ARGS P, t->d_hblk, t->d_ranges, t->d_row_ranges, t->d_cap_seg, t->d_cap_rad, t->d_lut, t->ctx->d_thresh, t->d_work, t->d_work_count, \
-                     rc_lo, rc_hi, t->d_rgba, write_vis ? t->d_vis : (uint32_t *)nullptr, stats, t->d_last_blocks, redo_count, t->d_redo
+        hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis);
+        // one persistent workgroup per CU (a 1024-thread workgroup with 70 KB of LDS fills one), the fast variant, works through
+        // the items; then a handful of persistent workgroups of the complete variant take the items that met a clipped or
+        // oversized primitive (normally none)
+        uint32_t *redo_count = S.work_count + 3;
+        const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount), ntiles + kSplitBudget)),
+                   few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
+#define VF_TILE_ARGS P, t->d_hblk, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
+                     rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, redo_count, S.redo
         if (write_vis) {
-            hipLaunchKernelGGL((k_tile<true, false>), all_items, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<true, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
             hipLaunchKernelGGL((k_tile<true, true>), few, threads, 0, s, VF_TILE_ARGS);
         } else {
-            hipLaunchKernelGGL((k_tile<false, false>), all_items, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
             hipLaunchKernelGGL((k_tile<false, true>), few, threads, 0, s, VF_TILE_ARGS);
         }
 #undef VF_TILE_ARGS
     }
-    if (t->timing) { if (!ntiles) VF_HIP_TRY(hipEventRecord(ev[2], s)); VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
+    if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
+    VF_HIP_TRY(hipEventRecord(S.drawn, s));
     VF_HIP_TRY(hipGetLastError());
     t->last_stream = s;
     t->rendered = true;
@@ -641,7 +682,7 @@ int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
     uint32_t n = 0;
-    VF_HIP_TRY(hipMemcpy(&n, t->d_work_count, sizeof n, hipMemcpyDeviceToHost));
+    VF_HIP_TRY(hipMemcpy(&n, t->ps[(t->frame_no - 1u) & 1u].work_count, sizeof n, hipMemcpyDeviceToHost));
     if (n > max_items) n = max_items;
     if (n) VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *count = n;
@@ -686,12 +727,18 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
         VF_HIP_TRY(hipEventSynchronize(t->ev[f][3]));
         VF_HIP_TRY(hipEventElapsedTime(&a, t->ev[f][0], t->ev[f][1]));
         VF_HIP_TRY(hipEventElapsedTime(&b, t->ev[f][1], t->ev[f][2]));
-        VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][2], t->ev[f][3]));
+        VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][4], t->ev[f][3]));      // clear + tile kernels, on the caller's stream
         VF_HIP_TRY(hipEventElapsedTime(&d, t->ev[f][0], t->ev[f][3]));
         ranges += a; plan += b; tile += c; total += d;
     }
     out->ranges_ms = (float)(ranges / nf); out->plan_ms = (float)(plan / nf); out->tile_ms = (float)(tile / nf);
     out->total_ms = (float)(total / nf);
+    if (nf >= 2 && t->timed_frames <= (uint32_t)vf_terrain::kTimingRing) {
+        // frames rendered back to back overlap (frame f+1 plans while frame f draws): the frame period is what a frame costs
+        float span = 0;
+        VF_HIP_TRY(hipEventElapsedTime(&span, t->ev[0][3], t->ev[nf - 1][3]));
+        out->total_ms = span / (float)(nf - 1);
+    }
     out->frames = nf;
     uint32_t c[4];
     VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));

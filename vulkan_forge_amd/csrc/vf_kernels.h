@@ -568,8 +568,8 @@ __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_
 // Weights are FEEDBACK: the time (10 ns ticks, summed over its strips) k_tile spent on the tile in the previous frame
 // (0 on the first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
 // never the result, so a stale value after a camera jump costs time, not correctness.
-__global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ rgba,
-                                              uint32_t *__restrict__ vis_out, uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
+__global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ background,
+                                              uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                               const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
                                               const uint32_t *__restrict__ rc_hi)
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     const uint32_t total = s_hits;
     if (total) {
         if (threadIdx.x == 0) {
+            background[blockIdx.x] = 0u;
             const uint32_t seen = last_blocks[blockIdx.x], mean = *last_mean;
             const uint32_t weight = seen ? seen : total;
             // strips: 1, 2, 4, 8 or 16.  `mean` holds the split quantum published by k_plan_sort: four times the work one
@@ -609,8 +610,19 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
         }
         return;
     }
-    // background tile: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
-    // (this pass is pure HBM write bandwidth: 49 MiB of the C4 default frame); edge tiles and odd widths go pixel by pixel.
+    // background tile: only flagged here.  The plan kernels touch nothing but plan state, so they may run on a side stream
+    // while the previous frame is still being drawn; k_clear, on the frame's own stream, does the clearing.
+    if (threadIdx.x == 0) background[blockIdx.x] = 1u;
+}
+
+// Background tiles: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
+// (this pass is pure HBM write bandwidth: 49 MiB of the C4 default frame); edge tiles and odd widths go pixel by pixel.
+__global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__restrict__ background, uint32_t *__restrict__ rgba,
+                                               uint32_t *__restrict__ vis_out)
+{
+    if (background[blockIdx.x] == 0u) return;
+    int32_t px_lo, px_hi, py_lo, py_hi;
+    const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
     const int32_t w = px_hi - px_lo + 1, h = py_hi - py_lo + 1;
     if (w == kTileW && (tp.out_stride & 3u) == 0u && (tp.out_base & 3u) == 0u && (reinterpret_cast<uintptr_t>(rgba) & 15u) == 0u &&
         (!vis_out || (reinterpret_cast<uintptr_t>(vis_out) & 15u) == 0u)) {
