@@ -33,7 +33,7 @@ def fold(d):
         out["vf::k_tile" if k.startswith("vf::k_tile<false") else k] = out.get("vf::k_tile" if k.startswith("vf::k_tile<false") else k, 0) + v
     return out
 f, w = fold(f), fold(w)
-frame = ["vf::k_block_boxes", "vf::k_plan", "vf::k_plan_sort", "vf::k_tile"]
+frame = ["vf::k_block_boxes", "vf::k_plan", "vf::k_plan_sort", "vf::k_clear", "vf::k_tile"]
 fetch_kib = sum(f.get(k, 0) for k in frame)
 write_kib = sum(w.get(k, 0) for k in frame)
 tile_f, tile_w = f.get("vf::k_tile", 0), w.get("vf::k_tile", 0)
