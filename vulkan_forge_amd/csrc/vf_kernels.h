@@ -754,10 +754,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     VF_PH_INIT
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
+    uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
+    if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
-    uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
-    if (COMPLETE && redo_at >= *redo_count) return;
 #if VF_PERSISTENT
     const uint32_t nwork = *work_count;
     uint32_t pulled = 0;
