@@ -26,7 +26,7 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #define VF_SPLIT_QUANTUM_X2 3
 #endif
 #ifndef VF_RESCAN_EVERY
-#define VF_RESCAN_EVERY 2
+#define VF_RESCAN_EVERY 1
 #endif
 constexpr int kMaxTileCols = 256;                 // frame width <= 16384 (vf_terrain_create)
 constexpr int kPhaseSlots = 16;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
