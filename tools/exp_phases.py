@@ -12,7 +12,7 @@ names = ["setup", "pull/cull", "vertex", "classify", "span raster", "completion/
 t = cabi.Terrain(W, H, G, lut, lib=cabi.load(sys.argv[1])); t.set_height(h)
 for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
-    for _ in range(6): t.render()
+    for _ in range(24): t.render()
     t.enable_timing(True); t.render(); tm = t.timings(); ph = t.phase_cycles().astype(float); it = t.item_stats(); t.enable_timing(False)
     cnt = ph[8:]; ph = ph[:8]
     tot = ph.sum()

@@ -19,7 +19,7 @@ def makespan(times, machines):
 
 for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
-    for _ in range(6): t.render()
+    for _ in range(24): t.render()
     t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
     ms = it[:, 3] * 1e-5                                   # raster + fragment, launch order
     ideal = makespan(ms, 256)

@@ -15,7 +15,7 @@ for cam in ("default", "fill"):
         if n == 1: t.set_shard(0, 1, 64)
         else: t.set_tile_shard(r, n, 3)
         lay = cabi.tile_layout(W, H, r, n, 3, lib=t.lib) if n > 1 else None
-        for _ in range(6): t.render()
+        for _ in range(24): t.render()
         t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
         ms = it[:, 2] * 1e-5
         order = np.argsort(-ms)[:12]
