@@ -501,6 +501,32 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const floa
 
 // One wave rescans the whole tile: which pixels are owned by a primitive with (id + 1) >= first_id?  Those can never
 // change again (only lower ids remain to be drawn).  Row masks by ballot, column masks by OR.  Returns the count.
+// Frontier rescan by one wave while the others keep rasterising: like rescan_final over the whole tile, but rows whose
+// pixels were all final at an earlier publication are not looked at again (final stays final) -- as a tile fills up, a
+// rescan costs less and less.  `row_full` = the row mask of a fully final row (the low `width` bits).
+__device__ __forceinline__ uint32_t rescan_open_rows(uint32_t *vis, uint32_t *colfin, uint32_t *rowfin, uint32_t lane, uint32_t first_id,
+                                                     uint64_t row_full, int32_t height)
+{
+    const uint64_t mine = (int32_t)lane < height ? load_mask(rowfin, (int32_t)lane) : row_full;     // lane r looks after row r
+    unsigned long long todo = __ballot(mine != row_full);
+    uint64_t colbits = 0;
+    while (todo) {
+        const int32_t ly = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const bool fin = ((row_full >> lane) & 1ull) && vis[vis_index((int32_t)lane, ly)] >= first_id;
+        const unsigned long long rm = __ballot(fin);
+        if (lane == 0) { rowfin[2 * ly] = (uint32_t)rm; rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
+        colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
+    }
+    if ((uint32_t)colbits) atomicOr(&colfin[2 * lane], (uint32_t)colbits);
+    if ((uint32_t)(colbits >> 32)) atomicOr(&colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
+    __builtin_amdgcn_wave_barrier();
+    uint32_t nfinal = (int32_t)lane < height ? (uint32_t)__popcll(load_mask(rowfin, (int32_t)lane)) : 0u;   // rows as they stand now
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nfinal += __shfl_xor(nfinal, o);
+    return nfinal;
+}
+
 __device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin, uint32_t *rowfin, uint32_t lane, uint32_t first_id,
                                                  int32_t row_begin, int32_t row_end)
 {
@@ -784,6 +810,7 @@ next_item:                                                 // (only the COMPLETE
     const int32_t tile_x0 = T.px_lo;                       // the tile's left edge (T.px_lo becomes the strip's below)
     work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2..16 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
+    const uint64_t row_full = ~0ull >> (63 - (T.px_hi - T.px_lo));   // row mask of a fully final row of this tile / strip
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
     for (int k = tid; k < kTileW * 2; k += kTileThreads) s_colfin[k] = 0u;
@@ -1031,7 +1058,7 @@ next_item:                                                 // (only the COMPLETE
             const uint32_t pub = *v_published;
             if (fr > pub && (fr - pub >= (uint32_t)kRescanEvery || fr == nsteps)) {
                 // steps 0 .. fr-1 are complete: everything owned by ids >= first id of step fr-1 is final
-                const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], 0, kTileH);
+                const uint32_t nfinal = rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, T.py_hi - T.py_lo + 1);
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) s_done = 1u; }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
