@@ -159,7 +159,7 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items, uint32_t *count);
 /* diagnostics, only in libraries built with -DVF_PHASE_PROF (VF_ERR_INVALID otherwise): shader-clock cycles summed over
  * all waves of the last frame's tile kernel, per phase (set-up, pull/cull, vertex stage, classification, span raster,
- * completion/rescan, end-of-chunk wait, fragment stage); n <= 16 */
+ * completion/rescan, end-of-chunk wait, fragment stage), then 8 event counts, then up to 8 parts of the set-up phase; n <= 32 */
 int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n);
 
 /* ---- grid_generate ----------------------------------------------------------------------- */

@@ -238,9 +238,10 @@ class Terrain:
         return out
 
     def phase_cycles(self):
-        """(16,) u64: [0:8] shader-clock cycles per phase summed over waves, [8:16] event counts (libraries built with -DVF_PHASE_PROF only)."""
-        out = np.zeros(16, np.uint64)
-        self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 16))
+        """(32,) u64: [0:8] shader-clock cycles per phase summed over waves, [8:16] event counts, [16:24] parts of the set-up phase, [24:28] wave-level executions of the line loop's parts
+        (libraries built with -DVF_PHASE_PROF only)."""
+        out = np.zeros(32, np.uint64)
+        self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 32))
         return out
 
     def timings(self):

@@ -29,7 +29,7 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #define VF_RESCAN_EVERY 1
 #endif
 constexpr int kMaxTileCols = 256;                 // frame width <= 16384 (vf_terrain_create)
-constexpr int kPhaseSlots = 16;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
+constexpr int kPhaseSlots = 32;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
 constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 

@@ -216,7 +216,7 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
 #ifdef VF_PHASE_PROF
-struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips; };
+struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach; };
 #define VF_RC_ARG , RasterCounts &RC
 #define VF_RC(...) __VA_ARGS__
 #else
@@ -260,8 +260,9 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
     for (int32_t o = sub; o <= n_outer; o += nsub) {
         const uint64_t done = load_mask(fin, o_base + o);
         const uint64_t open = ~done & seg;
-        VF_RC(RC.lines++;)
+        VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;)
         if (open == 0ull) continue;
+        VF_RC(RC.trips++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s1++;)
         // ---- stage 1: conservative span from FP32 crossing estimates (exact alpha, relative error ~2^-22 => |error| < 1/4
         //      inside the clamp range): true lo is one of k, k+1, k+2; true hi one of k+1, k, k-1, k-2 ----
         double alpha[3];
@@ -278,7 +279,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         if (lo_a > hi_a) continue;
         if ((bit_range(i_base + lo_a, i_base + hi_a) & open) == 0ull) continue;   // nothing this line could still change
         // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
-        VF_RC(RC.solved++;)
+        VF_RC(RC.solved++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s2++;)
         int32_t lo = 0, hi = n_inner;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -299,6 +300,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         while (bits) {
             const int32_t k = __builtin_ctzll(bits);
             bits &= bits - 1;
+            VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_paint++;)
             atomicMax(&T.vis[cols ? vis_index(ol, k) : vis_index(k, ol)], word);
         }
     }
@@ -347,7 +349,7 @@ __device__ __noinline__ void raster_generic(const GVert v[3], float hw, float hh
 
 // classification of one primitive against the tile: 0 = nothing to draw, 1 = fast path, 2 = generic path
 __device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uint32_t fl1, uint32_t fl2, int32_t X0, int32_t Y0,
-                                             int32_t X1, int32_t Y1, int32_t X2, int32_t Y2)
+                                             int32_t X1, int32_t Y1, int32_t X2, int32_t Y2 VF_RC_ARG)
 {
     const uint32_t any = fl0 | fl1 | fl2, all = fl0 & fl1 & fl2;
     if (any & F_BAD) return 0;                            // non-finite clip coordinate: primitive dropped
@@ -368,8 +370,13 @@ __device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uin
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
     const int32_t o0 = cols ? px0 - T.px_lo : py0 - T.py_lo, o1 = cols ? px1 - T.px_lo : py1 - T.py_lo;
     const uint64_t seg = cols ? bit_range(py0 - T.py_lo, py1 - T.py_lo) : bit_range(px0 - T.px_lo, px1 - T.px_lo);
-    for (int32_t o = o0; o <= o1; ++o)
-        if (~load_mask(fin, o) & seg) return 1;
+    VF_RC(RC.c_reach++;)
+    // four lines per step: the loop is a chain of LDS latencies (load, test, branch), not of arithmetic
+    for (int32_t o = o0; o <= o1; o += 4) {
+        VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_cls++;)
+        const uint64_t all4 = load_mask(fin, o) & load_mask(fin, min(o + 1, o1)) & load_mask(fin, min(o + 2, o1)) & load_mask(fin, min(o + 3, o1));
+        if (~all4 & seg) return 1;
+    }
     return 0;
 }
 
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 //      conservative); a fully final tile stops early;
 //   5. fragment stage on the LDS tile.
 #ifdef VF_PHASE_PROF   // diagnostics build: per-phase shader-clock cycles and event counts (vf_terrain_debug_phase_cycles)
-#define VF_PH_INIT uint64_t ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();
+#define VF_PH_INIT uint64_t ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..11: parts of the set-up
 #define VF_PH(p) { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[p] += ph_now - ph_last; ph_last = ph_now; }
 #else
 #define VF_PH_INIT
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     VF_PH_INIT
-    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
+    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
@@ -794,6 +801,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
         if (pulled >= nwork) return;
     }
 next_item:
+    VF_PH(12)                                              // hand-over: wait for the other waves, pull the next item
     const uint32_t item_idx = COMPLETE ? redo[redo_at] : pulled;
 #else
 next_item:                                                 // (only the COMPLETE variant ever comes back here)
@@ -818,6 +826,7 @@ next_item:                                                 // (only the COMPLETE
     if (tid < 16) s_rows[tid] = 0ull;
     if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
     __syncthreads();
+    VF_PH(13)                                              // item record, tile state
     // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
     for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
         const uint32_t r = base + tid;
@@ -831,6 +840,7 @@ next_item:                                                 // (only the COMPLETE
         if (lane == 0 && m) s_rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
     }
     __syncthreads();
+    VF_PH(14)                                              // row mask
 
     // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands word 15 - w ----
     uint32_t nrows_total = 0;
@@ -847,6 +857,7 @@ next_item:                                                 // (only the COMPLETE
     }
     __syncthreads();
 
+    VF_PH(8)                                                // item start, tile state, row list
     const uint32_t hit_words = (P.nb + 63u) / 64u;
     volatile uint32_t *v_pending = s_pending;
     volatile uint32_t *v_done = &s_done, *v_frontier = &s_frontier, *v_published = &s_published;
@@ -912,7 +923,9 @@ next_item:                                                 // (only the COMPLETE
                 if (lane == 0 && k < nrowsteps) { s_cnt[k] = cnt[r]; s_firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
             }
         }
+        VF_PH(9)                                            // candidate tests
         __syncthreads();
+        VF_PH(10)                                           // ... waiting for the slowest wave
         // ---- chunk set-up 2: every wave scans the row counts for itself (two 64-row halves), so all agree on the list offsets
         //      and on how many rows fit the list without another barrier; rows that do not fit wait for the next chunk ----
         static_assert(kMaxSteps == 128, "the offset scan below handles two 64-row halves");
@@ -945,6 +958,7 @@ next_item:                                                 // (only the COMPLETE
             if (lane == 0) s_pending[k] = cnt;
         }
         cursor += nsteps;
+        VF_PH(11)                                           // scan + list fill
         __syncthreads();
         VF_PH(0)
 
@@ -1000,8 +1014,8 @@ next_item:                                                 // (only the COMPLETE
                         const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
                         const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
                         const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
-                        k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);          // (a, c, b)
-                        k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);          // (b, c, d)
+                        k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb VF_RC(, RC));          // (a, c, b)
+                        k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd VF_RC(, RC));          // (b, c, d)
                         if (!COMPLETE && (k0 == 2 || k1 == 2)) s_redo = 1u;                  // rare: clipped / oversized -> the COMPLETE launch
                         if constexpr (COMPLETE) if (k0 == 2 || k1 == 2) {
                             const uint32_t prim = 2u * (j * P.nm1 + i);
@@ -1105,21 +1119,7 @@ next_item:                                                 // (only the COMPLETE
         rgba[o] = id ? shade_pixel<COMPLETE>(P, hblk, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
-#ifdef VF_PHASE_PROF
     VF_PH(7)
-    if (stats) {
-        unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + 4 + 4 * ((size_t)P.ntx * P.nty + kSplitBudget));
-        if (lane == 0) {
-            for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
-            atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
-            atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
-        }
-        atomicAdd(&ph[11], (unsigned long long)RC.lines); atomicAdd(&ph[12], (unsigned long long)RC.solved);
-        atomicAdd(&ph[13], (unsigned long long)RC.painted); atomicAdd(&ph[14], (unsigned long long)RC.paint_lines);
-        for (int p = 0; p < 8; ++p) ph_acc[p] = 0;           // flushed per item: a persistent workgroup comes here once per item
-        RC = RasterCounts{0, 0, 0, 0, 0, 0}; rc_nsurv = rc_iters = rc_live = rc_empty = 0;
-    }
-#endif
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
@@ -1138,6 +1138,27 @@ next_item:                                                 // (only the COMPLETE
         __syncthreads();
         pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
         if (pulled < nwork) goto next_item;
+    }
+#endif
+#ifdef VF_PHASE_PROF   // one flush per workgroup, after its last item (per-item flushes would perturb the hand-over they measure)
+    if (stats) {
+        unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + 4 + 4 * ((size_t)P.ntx * P.nty + kSplitBudget));
+        if (lane == 0) {
+            for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
+            for (int p = 8; p < 16; ++p) atomicAdd(&ph[8 + p], (unsigned long long)ph_acc[p]);
+            atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
+            atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
+        }
+        uint32_t rcs[4] = { RC.lines, RC.solved, RC.painted, RC.trips };   // (paint_lines gave way to: lines with an open pixel in their bounding range)
+        for (int c = 0; c < 4; ++c) {
+            for (int o = 32; o > 0; o >>= 1) rcs[c] += __shfl_xor(rcs[c], o);
+            if (lane == 0) atomicAdd(&ph[11 + c], (unsigned long long)rcs[c]);
+        }
+        uint32_t wcs[6] = { RC.w_iter, RC.w_s1, RC.w_s2, RC.w_paint, RC.w_cls, RC.c_reach };   // wave-level executions of the line loop's parts
+        for (int c = 0; c < 6; ++c) {
+            for (int o = 32; o > 0; o >>= 1) wcs[c] += __shfl_xor(wcs[c], o);
+            if (lane == 0) atomicAdd(&ph[24 + c], (unsigned long long)wcs[c]);
+        }
     }
 #endif
 }
