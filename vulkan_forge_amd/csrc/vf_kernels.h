@@ -372,10 +372,15 @@ __device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uin
     const uint64_t seg = cols ? bit_range(py0 - T.py_lo, py1 - T.py_lo) : bit_range(px0 - T.px_lo, px1 - T.px_lo);
     VF_RC(RC.c_reach++;)
     // four lines per step: the loop is a chain of LDS latencies (load, test, branch), not of arithmetic
-    for (int32_t o = o0; o <= o1; o += 4) {
+#ifndef VF_CLS_LINES
+#define VF_CLS_LINES 4
+#endif
+    for (int32_t o = o0; o <= o1; o += VF_CLS_LINES) {
         VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_cls++;)
-        const uint64_t all4 = load_mask(fin, o) & load_mask(fin, min(o + 1, o1)) & load_mask(fin, min(o + 2, o1)) & load_mask(fin, min(o + 3, o1));
-        if (~all4 & seg) return 1;
+        uint64_t all = load_mask(fin, o);
+#pragma unroll
+        for (int d = 1; d < VF_CLS_LINES; ++d) all &= load_mask(fin, min(o + d, o1));
+        if (~all & seg) return 1;
     }
     return 0;
 }
@@ -517,13 +522,24 @@ __device__ __forceinline__ uint32_t rescan_open_rows(uint32_t *vis, uint32_t *co
     const uint64_t mine = (int32_t)lane < height ? load_mask(rowfin, (int32_t)lane) : row_full;     // lane r looks after row r
     unsigned long long todo = __ballot(mine != row_full);
     uint64_t colbits = 0;
-    while (todo) {
-        const int32_t ly = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const bool fin = ((row_full >> lane) & 1ull) && vis[vis_index((int32_t)lane, ly)] >= first_id;
-        const unsigned long long rm = __ballot(fin);
-        if (lane == 0) { rowfin[2 * ly] = (uint32_t)rm; rowfin[2 * ly + 1] = (uint32_t)(rm >> 32); }
-        colbits |= (uint64_t)(fin ? 1u : 0u) << ly;
+    const bool in_row = (row_full >> lane) & 1ull;
+    while (todo) {                                         // four rows per trip: their LDS reads are in flight together
+        int32_t ly[4];
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ly[k] = todo ? __builtin_ctzll(todo) : -1;
+            todo &= todo - 1;                              // (0 stays 0)
+            v[k] = ly[k] >= 0 ? vis[vis_index((int32_t)lane, ly[k])] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ly[k] < 0) break;                          // uniform
+            const bool fin = in_row && v[k] >= first_id;
+            const unsigned long long rm = __ballot(fin);
+            if (lane == 0) { rowfin[2 * ly[k]] = (uint32_t)rm; rowfin[2 * ly[k] + 1] = (uint32_t)(rm >> 32); }
+            colbits |= (uint64_t)(fin ? 1u : 0u) << ly[k];
+        }
     }
     if ((uint32_t)colbits) atomicOr(&colfin[2 * lane], (uint32_t)colbits);
     if ((uint32_t)(colbits >> 32)) atomicOr(&colfin[2 * lane + 1], (uint32_t)(colbits >> 32));
