@@ -232,3 +232,31 @@ def test_cabi_misuse_reports_errors(luts):
     lib.vf_terrain_destroy(t); lib.vf_terrain_destroy(None)
     lib.vf_ctx_destroy(ctx); lib.vf_ctx_destroy(None)
     assert lib.vf_ctx_create(99, C.byref(ctx)) != cabi.VF_OK                          # no such device
+
+
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_large_readback_goes_through_the_pinned_ring_unchanged(luts, monkeypatch, threads):
+    """Frames of 8 MiB and more are read back through a ring of pinned chunks by a few host threads: every byte must arrive,
+    also when the last chunk is short, when there are more chunks than ring slots, and for a row range."""
+    from vulkan_forge_amd import cabi
+    monkeypatch.setenv("VF_COPY_THREADS", threads)
+    W, H, G = 3000, 3301, 96                                      # 39.6 MB: five chunks, the last one short
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    rng = np.random.default_rng(5)
+    t.set_height((rng.random((G, G), dtype=np.float32) - np.float32(0.5)) * np.float32(0.4))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    t.set_uniforms(b.camera_uniforms("fill", W, H))
+    t.render(); t.sync()
+    want = np.empty((H, W, 4), np.uint8)                          # reference: pieces below 8 MiB take the plain copy
+    for y0 in range(0, H, 600):
+        rows = min(600, H - y0)
+        t._check(t.lib.vf_terrain_read_rgba(t.t, want[y0:].ctypes.data, y0, rows))
+    assert len(np.unique(want.reshape(-1, 4), axis=0)) > 100      # a real picture, not a cleared frame
+    got = np.empty((H, W, 4), np.uint8)
+    t._check(t.lib.vf_terrain_read_rgba(t.t, got.ctypes.data, 0, H))
+    assert np.array_equal(got, want)
+    part = np.full((1500, W, 4), 7, np.uint8)
+    t._check(t.lib.vf_terrain_read_rgba(t.t, part.ctypes.data, 1001, 1500))
+    assert np.array_equal(part, want[1001:2501])

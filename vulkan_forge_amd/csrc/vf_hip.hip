@@ -10,6 +10,9 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
+#include <memory>
+#include <thread>
 
 using namespace vf;
 
@@ -111,8 +114,8 @@ struct vf_terrain {
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint8_t *d_png = nullptr, *h_png = nullptr;   // PNG scanlines of the last frame: device, pinned host
-    uint8_t *h_stage = nullptr;                   // 2 x kStageChunk pinned bytes: device -> pageable host copies go through here
-    hipEvent_t stage_ev[2] = { nullptr, nullptr };
+    uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
+    hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     bool shard_tiles = false;
     uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
@@ -605,24 +608,61 @@ int vf_terrain_sync(vf_terrain *t)
 // host memcpy of chunk k, and nothing is allocated or registered per call (the reference maps a fresh buffer per call,
 // src/terrain/mod.rs:446-451).
 constexpr size_t kStageChunk = 8u << 20;
+constexpr size_t kStageSlots = 4;
+static unsigned copy_threads()
+{
+    if (const char *e = std::getenv("VF_COPY_THREADS")) { const int v = std::atoi(e); if (v >= 1) return (unsigned)std::min(v, 16); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(4u, hw > 1 ? hw - 1 : 1u));
+}
+// Device -> pageable host memory through a ring of pinned chunks: the DMA engine fills chunk k + 1 .. k + 3 while host threads
+// move chunk k out (a frame-sized destination is usually fresh memory: the copy out is page-fault bound, which is why it is
+// spread over a few threads).  The calling thread only orchestrates: it enqueues a chunk once every thread is done with the
+// chunk that used the slot before.
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
     if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
-    if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, 2 * kStageChunk, hipHostMallocDefault));
+    if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, kStageSlots * kStageChunk, hipHostMallocDefault));
     for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
-    for (size_t i = 0; i <= nchunks; ++i) {
-        if (i < nchunks) {
-            const size_t len = i + 1 == nchunks ? n - i * kStageChunk : kStageChunk;
-            VF_HIP_TRY(hipMemcpyAsync(t->h_stage + (i & 1) * kStageChunk, src + i * kStageChunk, len, hipMemcpyDeviceToHost, s));
-            VF_HIP_TRY(hipEventRecord(t->stage_ev[i & 1], s));
+    const unsigned nthreads = copy_threads();
+    auto chunk_len = [&](size_t k) { return k + 1 == nchunks ? n - k * kStageChunk : kStageChunk; };
+    std::atomic<size_t> enqueued{0};                       // chunks whose copy + event are on the stream
+    std::unique_ptr<std::atomic<uint32_t>[]> done(new std::atomic<uint32_t>[nchunks]);
+    for (size_t k = 0; k < nchunks; ++k) done[k].store(0, std::memory_order_relaxed);
+    std::atomic<int> failed{0};
+    const int device = t->ctx->device;
+    auto worker = [&](unsigned w) {
+        (void)hipSetDevice(device);
+        for (size_t k = 0; k < nchunks; ++k) {
+            while (enqueued.load(std::memory_order_acquire) <= k) {
+                if (failed.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            if (hipEventSynchronize(t->stage_ev[k % kStageSlots]) != hipSuccess) failed.store(1);
+            else {
+                const size_t len = chunk_len(k);
+                const size_t lo = (len * w / nthreads) & ~(size_t)4095, hi = w + 1 == nthreads ? len : (len * (w + 1) / nthreads) & ~(size_t)4095;
+                if (hi > lo) std::memcpy(dst + k * kStageChunk + lo, t->h_stage + (k % kStageSlots) * kStageChunk + lo, hi - lo);
+            }
+            done[k].fetch_add(1, std::memory_order_release);
         }
-        if (i > 0) {
-            const size_t k = i - 1, len = k + 1 == nchunks ? n - k * kStageChunk : kStageChunk;
-            VF_HIP_TRY(hipEventSynchronize(t->stage_ev[k & 1]));
-            std::memcpy(dst + k * kStageChunk, t->h_stage + (k & 1) * kStageChunk, len);
-        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads);
+    for (unsigned w = 0; w < nthreads; ++w) pool.emplace_back(worker, w);
+    hipError_t err = hipSuccess;
+    for (size_t i = 0; i < nchunks && err == hipSuccess && !failed.load(); ++i) {
+        if (i >= kStageSlots)
+            while (done[i - kStageSlots].load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+        err = hipMemcpyAsync(t->h_stage + (i % kStageSlots) * kStageChunk, src + i * kStageChunk, chunk_len(i), hipMemcpyDeviceToHost, s);
+        if (err == hipSuccess) err = hipEventRecord(t->stage_ev[i % kStageSlots], s);
+        if (err == hipSuccess) enqueued.store(i + 1, std::memory_order_release);
     }
+    if (err != hipSuccess) failed.store(1);
+    for (auto &th : pool) th.join();
+    if (err != hipSuccess) return fail(VF_ERR_HIP, hipGetErrorString(err));
+    if (failed.load()) return fail(VF_ERR_HIP, "device -> host copy failed");
     return VF_OK;
 }
 
