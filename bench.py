@@ -162,6 +162,7 @@ def main():
     if ex is not None:
         ex.pending_frame = [False] * depth
 
+    exchanged = [False]
     SETTLE = 16  # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
                  # splitting; two frames old, because frames overlap) and needs a few frames of a new camera to converge; results never depend on it
 
@@ -169,6 +170,13 @@ def main():
         t.set_uniforms(camera_uniforms(camera, W, H))
         for _ in range(SETTLE):
             t.render(stream)
+        if world > 1 and not exchanged[0]:
+            # set-up, not steps: the first exchange creates the point-to-point channels (RCCL opens them lazily, about a second);
+            # like communicator creation it must not land in the timed region when the caller asks for --warmup 0
+            for _ in range(depth):
+                step()
+            flush()
+            exchanged[0] = True
         for _ in range(warmup):
             step()
         flush()
