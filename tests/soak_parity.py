@@ -1,0 +1,62 @@
+"""Parity soak on the GPU box: many seeded random frames (sizes, grids, cameras, clip planes, exaggeration, colormaps, both
+shade modes) rendered by the HIP path through the C-ABI and by the CPU oracle; reports every case whose visibility is not
+bit-exact or whose RGBA differs by more than 1 LSB.  Each case renders several frames on one handle, so the last frame --
+the one compared -- is planned with scheduling feedback (strips, heaviest-first order).  Test infrastructure, like tests/:
+the oracle is the checker here, nothing of it is shipped (a script, not collected by pytest: python tests/soak_parity.py).
+
+usage: soak_parity.py [first_seed] [cases] [time_budget_s]"""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle
+from vulkan_forge_amd import cabi
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 400.0
+luts = np.load(os.path.join(os.path.dirname(__file__), "golden", "colormaps_rgba8.npz"))
+t0 = time.time()
+bad, done, worst = [], 0, 0
+for seed in range(first, first + cases):
+    if time.time() - t0 > budget:
+        break
+    rng = np.random.default_rng(seed)
+    big = rng.random() < 0.15
+    W, H = (int(rng.integers(300, 1100)), int(rng.integers(200, 900))) if big else (int(rng.integers(1, 400)), int(rng.integers(1, 300)))
+    G = int(rng.choice([128, 200, 256, 384]) if big else rng.choice([2, 3, 5, 9, 16, 17, 33, 64, 96, 130]))
+    tex = (int(rng.integers(1, 300)), int(rng.integers(1, 300)))
+    h = (rng.random(tex, dtype=np.float32) - np.float32(0.5)) * np.float32(rng.choice([0.0, 0.2, 0.5, 1.0, 3.0]))
+    r = float(rng.choice([0.05, 0.6, 2.0, 3.0, 4.5, 9.0]))
+    th, ph = rng.uniform(0, 2 * math.pi), rng.uniform(-0.6, 1.5)
+    eye = (r * math.cos(th) * math.cos(ph), r * math.sin(ph), r * math.sin(th) * math.cos(ph))
+    target = tuple(float(v) for v in rng.uniform(-0.4, 0.4, 3))
+    fovy = float(rng.choice([20.0, 45.0, 60.0, 120.0, 170.0]))
+    znear = float(rng.choice([1e-3, 0.1, 0.5 * r]))
+    zfar = float(rng.choice([r + 0.3, 100.0, 1e4]))
+    try:
+        u = oracle.look_at_uniforms(1, W, H, eye, target, (0.0, 1.0, 0.0), fovy, znear, zfar)
+    except Exception:
+        continue                                               # degenerate camera (eye == target direction parallel to up, ...)
+    u[38] = float(rng.choice([1.0, 1.0, 0.0, 8.0, -2.0]))
+    u[36] = float(rng.choice([1.0, 1.0, 0.3, 2.5]))
+    cmap = str(rng.choice(["viridis", "magma", "terrain"]))
+    mode = int(rng.random() < 0.2)
+    ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts[cmap], nthreads=min(16, oracle.max_threads()), shade_mode=mode)
+    t = cabi.Terrain(W, H, G, luts[cmap])
+    try:
+        t.set_uniforms(u); t.set_shade_mode(mode); t.set_height(h)
+        for _ in range(4): t.render()
+        rgba = t.read_rgba(); vis = t.read_visibility()
+    finally:
+        t.close()
+    nv = int((vis != ref_vis).sum())
+    d = int(np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max()) if rgba.size else 0
+    worst = max(worst, d)
+    done += 1
+    if nv or d > 1:
+        bad.append((seed, W, H, G, nv, d))
+        print(f"MISMATCH seed={seed} {W}x{H} grid={G} mode={mode}: visibility differs at {nv} pixels, RGBA max diff {d}", flush=True)
+    if done % 25 == 0:
+        print(f"{done} cases, {len(bad)} mismatches, worst RGBA diff {worst} LSB, {time.time()-t0:.0f} s", flush=True)
+print(f"soak: {done} cases from seed {first}: {len(bad)} mismatches; worst RGBA difference {worst} LSB; {time.time()-t0:.0f} s")
+sys.exit(1 if bad else 0)
