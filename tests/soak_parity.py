@@ -16,7 +16,7 @@ cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 400.0
 luts = np.load(os.path.join(os.path.dirname(__file__), "golden", "colormaps_rgba8.npz"))
 t0 = time.time()
-bad, done, worst = [], 0, 0
+bad, done, worst, shards = [], 0, 0, 0
 for seed in range(first, first + cases):
     if time.time() - t0 > budget:
         break
@@ -47,8 +47,36 @@ for seed in range(first, first + cases):
         t.set_uniforms(u); t.set_shade_mode(mode); t.set_height(h)
         for _ in range(4): t.render()
         rgba = t.read_rgba(); vis = t.read_visibility()
+        shard_bad = ""
+        if rng.random() < 0.25:                                # the same frame from N ranks' shards, one after another on this GPU
+            n = int(rng.choice([2, 3, 4, 5, 8]))
+            if rng.random() < 0.5:
+                band = int(rng.choice([64, 128]))
+                out = np.zeros_like(rgba)
+                for rk in range(n):
+                    t.set_shard(rk, n, band)
+                    for _ in range(3): t.render()
+                    rows = np.flatnonzero(((np.arange(H) // band) % n) == rk)
+                    loc = t.read_rgba()
+                    out[rows] = loc
+                if not np.array_equal(out, rgba): shard_bad = f"bands n={n} band={band}"
+            else:
+                skew = int(rng.choice([1, 3, 5, 7]))
+                out = np.zeros_like(rgba)
+                for rk in range(n):
+                    t.set_tile_shard(rk, n, skew)
+                    for _ in range(3): t.render()
+                    tiles = t.read_tiles()
+                    for k, (tx, ty) in enumerate(cabi.tile_layout(W, H, rk, n, skew, lib=t.lib)):
+                        hh, ww = min(64, H - ty * 64), min(64, W - tx * 64)
+                        out[ty * 64:ty * 64 + hh, tx * 64:tx * 64 + ww] = tiles[k][:hh, :ww]
+                if not np.array_equal(out, rgba): shard_bad = f"tiles n={n} skew={skew}"
+            shards += 1
     finally:
         t.close()
+    if shard_bad:
+        bad.append((seed, W, H, G, -1, -1))
+        print(f"SHARD MISMATCH seed={seed} {W}x{H} grid={G}: {shard_bad}", flush=True)
     nv = int((vis != ref_vis).sum())
     d = int(np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max()) if rgba.size else 0
     worst = max(worst, d)
@@ -58,5 +86,5 @@ for seed in range(first, first + cases):
         print(f"MISMATCH seed={seed} {W}x{H} grid={G} mode={mode}: visibility differs at {nv} pixels, RGBA max diff {d}", flush=True)
     if done % 25 == 0:
         print(f"{done} cases, {len(bad)} mismatches, worst RGBA diff {worst} LSB, {time.time()-t0:.0f} s", flush=True)
-print(f"soak: {done} cases from seed {first}: {len(bad)} mismatches; worst RGBA difference {worst} LSB; {time.time()-t0:.0f} s")
+print(f"soak: {done} cases from seed {first} ({shards} of them also rendered as 2..8 band or tile shards and stitched): {len(bad)} mismatches; worst RGBA difference {worst} LSB; {time.time()-t0:.0f} s")
 sys.exit(1 if bad else 0)
