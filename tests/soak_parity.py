@@ -17,6 +17,7 @@ budget = float(sys.argv[3]) if len(sys.argv) > 3 else 400.0
 luts = np.load(os.path.join(os.path.dirname(__file__), "golden", "colormaps_rgba8.npz"))
 t0 = time.time()
 bad, done, worst, shards = [], 0, 0, 0
+HUGE = os.environ.get("VF_SOAK_HUGE") == "1"
 for seed in range(first, first + cases):
     if time.time() - t0 > budget:
         break
@@ -24,6 +25,9 @@ for seed in range(first, first + cases):
     big = rng.random() < 0.15
     W, H = (int(rng.integers(300, 1100)), int(rng.integers(200, 900))) if big else (int(rng.integers(1, 400)), int(rng.integers(1, 300)))
     G = int(rng.choice([128, 200, 256, 384]) if big else rng.choice([2, 3, 5, 9, 16, 17, 33, 64, 96, 130]))
+    if HUGE:                                                   # VF_SOAK_HUGE=1: frames and grids of the BASELINE configurations' size
+        W, H = int(rng.integers(1500, 4097)), int(rng.integers(1000, 4097))
+        G = int(rng.choice([512, 1024, 1500, 2048, 3000, 4096]))
     tex = (int(rng.integers(1, 300)), int(rng.integers(1, 300)))
     h = (rng.random(tex, dtype=np.float32) - np.float32(0.5)) * np.float32(rng.choice([0.0, 0.2, 0.5, 1.0, 3.0]))
     r = float(rng.choice([0.05, 0.6, 2.0, 3.0, 4.5, 9.0]))
@@ -45,7 +49,7 @@ for seed in range(first, first + cases):
     t = cabi.Terrain(W, H, G, luts[cmap])
     try:
         t.set_uniforms(u); t.set_shade_mode(mode); t.set_height(h)
-        for _ in range(4): t.render()
+        for _ in range(8 if HUGE else 4): t.render()
         rgba = t.read_rgba(); vis = t.read_visibility()
         shard_bad = ""
         if rng.random() < 0.25:                                # the same frame from N ranks' shards, one after another on this GPU
@@ -84,7 +88,7 @@ for seed in range(first, first + cases):
     if nv or d > 1:
         bad.append((seed, W, H, G, nv, d))
         print(f"MISMATCH seed={seed} {W}x{H} grid={G} mode={mode}: visibility differs at {nv} pixels, RGBA max diff {d}", flush=True)
-    if done % 25 == 0:
+    if done % (5 if HUGE else 25) == 0:
         print(f"{done} cases, {len(bad)} mismatches, worst RGBA diff {worst} LSB, {time.time()-t0:.0f} s", flush=True)
 print(f"soak: {done} cases from seed {first} ({shards} of them also rendered as 2..8 band or tile shards and stitched): {len(bad)} mismatches; worst RGBA difference {worst} LSB; {time.time()-t0:.0f} s")
 sys.exit(1 if bad else 0)
