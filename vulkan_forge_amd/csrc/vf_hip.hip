@@ -78,7 +78,7 @@ struct vf_ctx {
 struct vf_terrain {
     vf_ctx *ctx = nullptr;
     uint32_t W = 0, H = 0, n = 0;
-    uint32_t nb = 0, nblocks = 0;        // 16x16-cell blocks per side / in total
+    uint32_t nb = 0, nblocks = 0;        // 8x8-cell blocks per side / in total
     uint32_t ntx = 0, nty = 0;           // 64x64 screen tiles
     // shard
     uint32_t rank = 0, nranks = 1, band_h = kTileH, local_rows = 0, skew = 0;
@@ -368,9 +368,11 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     size_t bytes = (size_t)tw * th * sizeof(float);
     if ((size_t)t->tw * t->th != (size_t)tw * th || t->d_height != t->d_height_own) {
-        if (t->d_height_own) VF_HIP_TRY(hipFree(t->d_height_own));
-        t->d_height_own = nullptr;
-        VF_HIP_TRY(hipMalloc(&t->d_height_own, bytes));
+        float *fresh = nullptr;                            // allocate first: a failure leaves the handle as it was
+        hipError_t e = hipMalloc(&fresh, bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("height texture allocation failed: ") + hipGetErrorString(e));
+        if (t->d_height_own) (void)hipFree(t->d_height_own);
+        t->d_height_own = fresh;
     }
     t->d_height = t->d_height_own;
     VF_HIP_TRY(hipMemcpyAsync(t->d_height_own, host_height, bytes, hipMemcpyHostToDevice, t->ctx->stream));
@@ -604,9 +606,6 @@ int vf_terrain_sync(vf_terrain *t)
     return VF_OK;
 }
 
-// Device -> pageable host memory through two pinned staging chunks owned by the handle: the DMA of chunk k+1 overlaps the
-// host memcpy of chunk k, and nothing is allocated or registered per call (the reference maps a fresh buffer per call,
-// src/terrain/mod.rs:446-451).
 constexpr size_t kStageChunk = 8u << 20;
 constexpr size_t kStageSlots = 4;
 static unsigned copy_threads()
@@ -618,7 +617,8 @@ static unsigned copy_threads()
 // Device -> pageable host memory through a ring of pinned chunks: the DMA engine fills chunk k + 1 .. k + 3 while host threads
 // move chunk k out (a frame-sized destination is usually fresh memory: the copy out is page-fault bound, which is why it is
 // spread over a few threads).  The calling thread only orchestrates: it enqueues a chunk once every thread is done with the
-// chunk that used the slot before.
+// chunk that used the slot before.  The ring is owned by the handle: nothing is allocated or registered per call (the
+// reference maps a fresh buffer per call, src/terrain/mod.rs:446-451).
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
     if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
