@@ -21,9 +21,11 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #ifndef VF_TILE_THREADS
 #define VF_TILE_THREADS 1024
 #endif
-// strip splitting quantum, in halves of the even per-item share of last frame's work (tuned on C4: 3 = 1.5 shares)
-#ifndef VF_SPLIT_QUANTUM_X2
-#define VF_SPLIT_QUANTUM_X2 3
+// strip splitting quantum, in quarters of the even per-item share of last frame's work (kTargetItems items = 4 per CU).  A tile stays
+// whole up to two quanta, i.e. up to VF_SPLIT_QUANTUM_X4 / 8 of a CU's even share of the frame: at 8 the heaviest whole tile alone
+// would take as long as a perfectly balanced frame, beyond it sets the frame time (C4: 6 -> 1.273 ms, 8 -> 1.258, 10 -> 1.45)
+#ifndef VF_SPLIT_QUANTUM_X4
+#define VF_SPLIT_QUANTUM_X4 7
 #endif
 #ifndef VF_RESCAN_EVERY
 #define VF_RESCAN_EVERY 1

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
     }
     __syncthreads();
     // split quantum: half of 4x the even share (a tile reaching 2 quanta is cut in two, 4 quanta in four, ...)
-    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X2 * s_sum / (2ull * kTargetItems)) : 0u;
+    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X4 * s_sum / (4ull * kTargetItems)) : 0u;
     for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // k_tile adds this frame's counts
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
