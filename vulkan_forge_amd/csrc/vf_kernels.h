@@ -22,9 +22,6 @@
 // block row r: after a block row has been rasterised, covered pixels are final.
 #pragma once
 #include "vf_device.h"
-#ifndef VF_PERSISTENT
-#define VF_PERSISTENT 1   // tile kernel: one persistent workgroup per CU pulls items (0: one workgroup per possible item)
-#endif
 
 namespace vf {
 
@@ -771,9 +768,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
                                                        uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo_count,
                                                        uint32_t *__restrict__ redo)
 {
-#if !VF_PERSISTENT
-    if (!COMPLETE && blockIdx.x >= *work_count) return;    // the launch covers the worst case; only the planned items have work
-#endif
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -807,7 +801,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
-#if VF_PERSISTENT
     const uint32_t nwork = *work_count;
     uint32_t pulled = 0;
     if (!COMPLETE) {
@@ -819,10 +812,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
 next_item:
     VF_PH(12)                                              // hand-over: wait for the other waves, pull the next item
     const uint32_t item_idx = COMPLETE ? redo[redo_at] : pulled;
-#else
-next_item:                                                 // (only the COMPLETE variant ever comes back here)
-    const uint32_t item_idx = COMPLETE ? redo[redo_at] : blockIdx.x;
-#endif
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[item_idx].x;
@@ -1147,7 +1136,6 @@ next_item:                                                 // (only the COMPLETE
         __syncthreads();                                   // the next item re-initialises the tile state
         if (redo_at < *redo_count) goto next_item;
     }
-#if VF_PERSISTENT
     else {
         __syncthreads();
         if (tid == 0) s_item = atomicAdd(work_count + 2, 1u);
@@ -1155,7 +1143,6 @@ next_item:                                                 // (only the COMPLETE
         pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
         if (pulled < nwork) goto next_item;
     }
-#endif
 #ifdef VF_PHASE_PROF   // one flush per workgroup, after its last item (per-item flushes would perturb the hand-over they measure)
     if (stats) {
         unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + 4 + 4 * ((size_t)P.ntx * P.nty + kSplitBudget));
