@@ -208,7 +208,8 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // below 2^53, so the arithmetic is exact.  For each line of the shorter bbox axis the covered span
 // along the longer axis is bounded by the three half-planes alpha_i + beta_i * r > 0; the crossing is
 // estimated in FP32 (error < 1/4 for quotients < 2^20, larger ones are clamped away) and then fixed up
-// with the exact FP64 edge value, so the span is exactly the set of covered pixel centres.
+// with the exact FP64 edge value, so the span is exactly the set of covered pixel centres.  The estimate
+// stage, which five lines in six do not survive, uses only the two edges that span the most lines.
 // Lines whose candidate pixels are all final (owned by a higher block row) are skipped unsolved, and
 // only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
@@ -229,10 +230,19 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
     const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
     const int32_t py0 = max((ymin + 127) >> 8, T.py_lo), py1 = min((ymax - 128) >> 8, T.py_hi);
     if (px0 > px1 || py0 > py1) return;
+    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
+    {   // Rotate the vertices so that edge 2 (v0 -> v1) is the one that spans the fewest lines: the estimate stage below leaves
+        // it out -- it only ever trims a line's span near one end of the triangle -- and the exact stage still applies it.
+        const int32_t c0 = cols ? X0 : Y0, c1 = cols ? X1 : Y1, c2 = cols ? X2 : Y2;
+        const int32_t e0 = abs(c2 - c1), e1 = abs(c0 - c2), e2 = abs(c1 - c0);
+        const bool left = e0 < e2 && e0 <= e1, right = !left && e1 < e2;      // (v1, v2, v0) / (v2, v0, v1): same orientation
+        const int32_t x0 = X0, y0 = Y0;
+        if (left) { X0 = X1; Y0 = Y1; X1 = X2; Y1 = Y2; X2 = x0; Y2 = y0; }
+        else if (right) { X0 = X2; Y0 = Y2; X2 = X1; Y2 = Y1; X1 = x0; Y1 = y0; }
+    }
     const double dX0 = X0, dY0 = Y0, dX1 = X1, dY1 = Y1, dX2 = X2, dY2 = Y2;
     const double area2 = fma(dX1 - dX0, dY2 - dY0, -((dY1 - dY0) * (dX2 - dX0)));
     if (area2 >= 0.0) return;                              // back-facing or degenerate
-    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
     const int32_t n_outer = cols ? px1 - px0 : py1 - py0, n_inner = cols ? py1 - py0 : px1 - px0;
     const int32_t o_base = cols ? px0 - T.px_lo : py0 - T.py_lo;     // tile-local index of outer line 0
     const int32_t i_base = cols ? py0 - T.py_lo : px0 - T.px_lo;     // tile-local index of inner offset 0
@@ -266,7 +276,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         int32_t kk[3];
         int32_t lo_a = 0, hi_a = n_inner;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 2; ++i) {                             // (edges 0 and 1: the two that span the most lines)
             alpha[i] = fma(SO[i], (double)o, base[i]);            // f_i at inner offset 0 (exact)
             kk[i] = (int32_t)floorf(fminf(fmaxf(-(float)alpha[i] * rSI[i], q_lo), q_hi));
             if (SI[i] > 0.0) lo_a = max(lo_a, kk[i]);
@@ -277,6 +287,8 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         if ((bit_range(i_base + lo_a, i_base + hi_a) & open) == 0ull) continue;   // nothing this line could still change
         // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
         VF_RC(RC.solved++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s2++;)
+        alpha[2] = fma(SO[2], (double)o, base[2]);
+        kk[2] = (int32_t)floorf(fminf(fmaxf(-(float)alpha[2] * rSI[2], q_lo), q_hi));
         int32_t lo = 0, hi = n_inner;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
