@@ -508,14 +508,14 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const floa
     const int32_t y0 = max((int32_t)b.y0, T.py_lo), y1 = min((int32_t)b.y1, T.py_hi);
     if (x0 > x1 || y0 > y1) return false;
     if (!capsule_hits_tile(cap_seg, cap_rad, T)) return false;
-    if (x1 - x0 <= y1 - y0) {
-        const uint64_t seg = bit_range(y0 - T.py_lo, y1 - T.py_lo);
-        for (int32_t c = x0 - T.px_lo; c <= x1 - T.px_lo; ++c)
-            if (~load_mask(T.colfin, c) & seg) return true;
-    } else {
-        const uint64_t seg = bit_range(x0 - T.px_lo, x1 - T.px_lo);
-        for (int32_t r = y0 - T.py_lo; r <= y1 - T.py_lo; ++r)
-            if (~load_mask(T.rowfin, r) & seg) return true;
+    // four lines of the shorter side per step, as in classify_prim: a chain of LDS latencies otherwise
+    const bool cols = x1 - x0 <= y1 - y0;
+    const uint32_t *fin = cols ? T.colfin : T.rowfin;
+    const int32_t o0 = cols ? x0 - T.px_lo : y0 - T.py_lo, o1 = cols ? x1 - T.px_lo : y1 - T.py_lo;
+    const uint64_t seg = cols ? bit_range(y0 - T.py_lo, y1 - T.py_lo) : bit_range(x0 - T.px_lo, x1 - T.px_lo);
+    for (int32_t o = o0; o <= o1; o += 4) {
+        const uint64_t all4 = load_mask(fin, o) & load_mask(fin, min(o + 1, o1)) & load_mask(fin, min(o + 2, o1)) & load_mask(fin, min(o + 3, o1));
+        if (~all4 & seg) return true;
     }
     return false;
 }
