@@ -221,6 +221,13 @@ struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips,
 #define VF_RC_ARG
 #define VF_RC(...)
 #endif
+// floor(x) as int32 in one instruction (V_CVT_FLR_I32_F32; the compiler emits v_floor_f32 + v_cvt_i32_f32 for (int)floorf(x))
+__device__ __forceinline__ int32_t floor_to_int(float x)
+{
+    int32_t k;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(x));
+    return k;
+}
 __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
                                             int32_t X2, int32_t Y2, int32_t sub, int32_t nsub VF_RC_ARG)
 {
@@ -278,7 +285,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                             // (edges 0 and 1: the two that span the most lines)
             alpha[i] = fma(SO[i], (double)o, base[i]);            // f_i at inner offset 0 (exact)
-            kk[i] = (int32_t)floorf(__builtin_amdgcn_fmed3f(-(float)alpha[i] * rSI[i], q_lo, q_hi));   // clamp in one instruction (q_lo < q_hi)
+            kk[i] = floor_to_int(__builtin_amdgcn_fmed3f(-(float)alpha[i] * rSI[i], q_lo, q_hi));   // clamp in one instruction (q_lo < q_hi)
             if (SI[i] > 0.0) lo_a = max(lo_a, kk[i]);
             else if (SI[i] < 0.0) hi_a = min(hi_a, kk[i] + 1);
             else if (alpha[i] <= 0.0) hi_a = -1;
@@ -288,7 +295,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int
         // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
         VF_RC(RC.solved++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s2++;)
         alpha[2] = fma(SO[2], (double)o, base[2]);
-        kk[2] = (int32_t)floorf(__builtin_amdgcn_fmed3f(-(float)alpha[2] * rSI[2], q_lo, q_hi));
+        kk[2] = floor_to_int(__builtin_amdgcn_fmed3f(-(float)alpha[2] * rSI[2], q_lo, q_hi));
         int32_t lo = 0, hi = n_inner;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
