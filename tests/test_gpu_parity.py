@@ -270,6 +270,29 @@ def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
         t.close()
 
 
+def test_orbiting_camera_back_to_back(cabi, oracle, luts):
+    """A camera that moves the picture by more than a tile per frame makes the plan wait for the previous frame's feedback
+    instead of overlapping it (vf_hip.hip: kFreshFeedbackPx); slow motion keeps the overlap.  Frames are queued back to back
+    without a read in between; the last one of each run must equal the oracle's."""
+    import math
+    W, H, G = 1280, 720, 512
+    h = heightmap(5, G)
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h)
+        for nposes, frames in ((48, 9), (720, 12)):                       # 7.5 degrees per frame, then 0.5
+            eyes = [(4.2 * math.cos(2 * math.pi * k / nposes), 2.0, 4.2 * math.sin(2 * math.pi * k / nposes)) for k in range(frames)]
+            us = [oracle.look_at_uniforms(1, W, H, e, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0, 0.1, 100.0) for e in eyes]
+            for u in us:
+                t.set_uniforms(u); t.render()
+            rgba = t.read_rgba()
+            ref_rgba, ref_vis = oracle.render_terrain(us[-1], W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
+            assert np.array_equal(rgba, ref_rgba), nposes
+            assert np.array_equal(t.read_visibility(), ref_vis), nposes
+    finally:
+        t.close()
+
+
 def test_maximum_grid_8192(cabi, oracle, luts):
     """Largest grid the C-ABI accepts (8192: 1024 x 1024 blocks, the limit of the tile kernel's 10-bit block indices):
     oracle parity at 2048 x 1536, and interleaved-tile shards that reassemble to the same frame."""

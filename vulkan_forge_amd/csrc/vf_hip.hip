@@ -85,6 +85,8 @@ struct vf_terrain {
     // uniforms
     float u[44];
     bool have_uniforms = false;
+    float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
+    bool have_drawn = false;
     // device state
     float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
     int32_t *d_txi = nullptr, *d_tyj = nullptr;
@@ -524,13 +526,45 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
 }
 
+// How far, in pixels, the terrain's footprint moved on the screen between two cameras (corners of the xz square at y = 0).
+// Scheduling feedback is per screen tile: once the picture has moved by about a tile, an older frame's tile times describe
+// other content.  A corner behind either camera counts as "moved".
+static float camera_shift_px(const vf_terrain *t, const float *a, const float *b)
+{
+    const float ext = 1.5f * std::fmax(t->u[36], 1e-8f);
+    float worst = 0.0f;
+    for (int c = 0; c < 4; ++c) {
+        const float p[4] = { (c & 1) ? ext : -ext, 0.0f, (c & 2) ? ext : -ext, 1.0f };
+        float xy[2][2];
+        for (int k = 0; k < 2; ++k) {
+            const float *u = k ? b : a;                    // column-major view (u[0..16)) and proj (u[16..32))
+            float v[4], q[4];
+            for (int r = 0; r < 4; ++r) v[r] = u[r] * p[0] + u[4 + r] * p[1] + u[8 + r] * p[2] + u[12 + r] * p[3];
+            for (int r = 0; r < 4; ++r) q[r] = u[16 + r] * v[0] + u[20 + r] * v[1] + u[24 + r] * v[2] + u[28 + r] * v[3];
+            if (!(q[3] > 1e-6f)) return 1e9f;
+            xy[k][0] = q[0] / q[3] * 0.5f * (float)t->W; xy[k][1] = q[1] / q[3] * 0.5f * (float)t->H;
+        }
+        worst = std::fmax(worst, std::fmax(std::fabs(xy[0][0] - xy[1][0]), std::fabs(xy[0][1] - xy[1][1])));
+    }
+    return worst;
+}
+constexpr float kFreshFeedbackPx = 48.0f;   // from here on (3/4 of a tile per frame) the plan waits for the previous frame's feedback
+
 static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 {
     FrameParams P;
     build_params(t, P);
     AxisTables A = axis(t);
     const uint32_t ntiles = t->local_tiles;
-    vf_terrain::PlanState &S = t->ps[t->frame_no++ & 1u];
+    const uint32_t set = t->frame_no++ & 1u;
+    vf_terrain::PlanState &S = t->ps[set], &O = t->ps[set ^ 1u];       // this frame's plan state, the previous frame's
+    // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
+    // a camera that moves the picture by most of a tile per frame waits for the previous frame instead and uses ITS feedback:
+    // the plan then costs its own time (k_plan + k_plan_sort after the tile kernel), stale feedback costs more (64-pose orbit
+    // at 1920x1080, grid 2048: 0.80 -> 0.70 ms per pose).
+    const bool fresh = t->have_drawn && camera_shift_px(t, t->u_drawn, t->u) > kFreshFeedbackPx;
+    std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
+    t->have_drawn = true;
     hipStream_t side = t->side;
     hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
     // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
@@ -551,8 +585,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (ntiles) {
         VF_HIP_TRY(hipMemsetAsync(S.work_count, 0, 4 * sizeof(uint32_t), side));
         uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
+        if (fresh) VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));   // (the block boxes above did not need to wait)
+        const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
-                           S.feedback, quantum, S.work_count + 1, rc_lo, rc_hi);
+                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
