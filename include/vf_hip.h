@@ -135,7 +135,9 @@ int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba);
  * The render pass of render_png (src/terrain/mod.rs:412-437, src/scene/mod.rs:280-298): clear to
  * linear (0.02,0.02,0.03,1), one indexed draw of 6(n-1)^2 indices, vs_main / raster / fs_main
  * (src/shaders/terrain.wgsl:44-91), sRGB store.  Leaves tightly packed RGBA8 (local rows) in HBM.
- * Asynchronous on `stream`.
+ * Asynchronous on `stream` (NULL = the context's stream): the output is complete when work queued on `stream` after this
+ * call runs.  Planning kernels run on a stream owned by the handle and may overlap the previous frame; how the frame's work
+ * is ordered and split follows the times measured on this handle's earlier frames -- that steers speed only, never a pixel.
  */
 int vf_terrain_render(vf_terrain *t, void *stream);
 int vf_terrain_sync(vf_terrain *t);
