@@ -588,7 +588,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         if (fresh) VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));   // (the block boxes above did not need to wait)
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
-                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi);
+                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, fresh ? 1u : 0u);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                                               uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                               const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
-                                              const uint32_t *__restrict__ rc_hi)
+                                              const uint32_t *__restrict__ rc_hi, uint32_t moving)
 {
     __shared__ uint32_t s_hits;
     int32_t px_lo, px_hi, py_lo, py_hi;
@@ -657,7 +657,22 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     if (total) {
         if (threadIdx.x == 0) {
             background[blockIdx.x] = 0u;
-            const uint32_t seen = last_blocks[blockIdx.x], mean = *last_mean;
+            uint32_t seen = last_blocks[blockIdx.x];
+            const uint32_t mean = *last_mean;
+            if ((seen == 0u || moving) && mean && P.nranks == 1u && !P.shard_tiles) {
+                // The camera moved.  A tile that is busy now but was background in the frame the feedback comes from would sort last
+                // and never be split, and what moved in is most likely what a neighbour held (the silhouette's heavy tiles
+                // wander): it takes the heaviest tile within two tiles' distance.  With a fast camera (`moving`: the plan runs
+                // after the previous frame, vf_hip.hip) every tile takes the heaviest of its 3 x 3 neighbourhood -- cutting a
+                // tile too fine costs some repeated block work, leaving a heavy one whole costs the frame's critical path.
+                const int32_t tx = (int32_t)tp.tx, ty = (int32_t)(blockIdx.x / P.ntx);
+                const int32_t reach = seen ? 1 : 2;
+                for (int32_t dy = -reach; dy <= reach; ++dy)
+                    for (int32_t dx = -reach; dx <= reach; ++dx) {
+                        const int32_t x = tx + dx, y = ty + dy;
+                        if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, last_blocks[(uint32_t)y * P.ntx + (uint32_t)x]);
+                    }
+            }
             const uint32_t weight = seen ? seen : total;
             // strips: 1, 2, 4, 8 or 16.  `mean` holds the split quantum published by k_plan_sort: four times the work one
             // item would carry if last frame's blocks were spread evenly over kTargetItems workgroups -- so a lightly loaded
