@@ -86,7 +86,7 @@ struct vf_terrain {
     float u[44];
     bool have_uniforms = false;
     float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
-    bool have_drawn = false;
+    bool have_drawn = false, camera_moving = false;
     // device state
     float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
     int32_t *d_txi = nullptr, *d_tyj = nullptr;
@@ -548,7 +548,7 @@ static float camera_shift_px(const vf_terrain *t, const float *a, const float *b
     }
     return worst;
 }
-constexpr float kFreshFeedbackPx = 48.0f;   // from here on (3/4 of a tile per frame) the plan waits for the previous frame's feedback
+constexpr float kFreshFeedbackPx = 24.0f;   // from here on (3/8 of a tile per frame) the plan waits for the previous frame's feedback
 
 static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 {
@@ -559,10 +559,15 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t set = t->frame_no++ & 1u;
     vf_terrain::PlanState &S = t->ps[set], &O = t->ps[set ^ 1u];       // this frame's plan state, the previous frame's
     // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
-    // a camera that moves the picture by most of a tile per frame waits for the previous frame instead and uses ITS feedback:
+    // a camera that moves the picture by a good part of a tile per frame waits for the previous frame instead and uses ITS feedback:
     // the plan then costs its own time (k_plan + k_plan_sort after the tile kernel), stale feedback costs more (64-pose orbit
-    // at 1920x1080, grid 2048: 0.80 -> 0.70 ms per pose).
-    const bool fresh = t->have_drawn && camera_shift_px(t, t->u_drawn, t->u) > kFreshFeedbackPx;
+    // at 1920x1080, grid 2048: 0.80 -> 0.61 ms per pose together with the dilated weights in k_plan; tools/exp_orbit.py).
+    if (t->have_drawn) {
+        const float shift = camera_shift_px(t, t->u_drawn, t->u);
+        if (shift > kFreshFeedbackPx) t->camera_moving = true;                 // hysteresis: frames that alternate between the two
+        else if (shift < 0.5f * kFreshFeedbackPx) t->camera_moving = false;    // modes get the worst of both
+    }
+    const bool fresh = t->camera_moving;
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
     hipStream_t side = t->side;
