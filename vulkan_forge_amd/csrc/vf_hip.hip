@@ -562,12 +562,14 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // a camera that moves the picture by a good part of a tile per frame waits for the previous frame instead and uses ITS feedback:
     // the plan then costs its own time (k_plan + k_plan_sort after the tile kernel), stale feedback costs more (64-pose orbit
     // at 1920x1080, grid 2048: 0.80 -> 0.61 ms per pose together with the dilated weights in k_plan; tools/exp_orbit.py).
+    float shift = 0.0f;
     if (t->have_drawn) {
-        const float shift = camera_shift_px(t, t->u_drawn, t->u);
+        shift = camera_shift_px(t, t->u_drawn, t->u);
         if (shift > kFreshFeedbackPx) t->camera_moving = true;                 // hysteresis: frames that alternate between the two
         else if (shift < 0.5f * kFreshFeedbackPx) t->camera_moving = false;    // modes get the worst of both
     }
     const bool fresh = t->camera_moving;
+    const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
     hipStream_t side = t->side;
@@ -593,7 +595,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         if (fresh) VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));   // (the block boxes above did not need to wait)
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
-                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, fresh ? 1u : 0u);
+                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
