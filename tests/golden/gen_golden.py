@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # tests/golden/ -> repository root
 sys.path.insert(0, ROOT)
 import oracle as O  # noqa: E402
 
