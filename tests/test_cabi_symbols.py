@@ -59,3 +59,20 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
                 assert "vf_oracle" not in text and "vfo_" not in text, f
+
+
+def test_only_tests_bench_and_entry_touch_the_oracle():
+    """Outside oracle/ itself, only tests/, bench.py (its cpu_baseline leg) and __graft_entry__.py (build + smoke) may import it:
+    the measurement probes under tools/ time and inspect the product alone."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    for top in ("tools", "vulkan_forge", "vshade"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py"):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+    for f in os.listdir(ROOT):
+        path = os.path.join(ROOT, f)
+        if f.endswith(".py") and path not in allowed:
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", open(path, errors="ignore").read(), flags=re.M), f
+
