@@ -86,7 +86,7 @@ struct vf_terrain {
     float u[44];
     bool have_uniforms = false;
     float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
-    bool have_drawn = false, camera_moving = false;
+    bool have_drawn = false, camera_moving = false, was_moving = false;
     // device state
     float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
     int32_t *d_txi = nullptr, *d_tyj = nullptr;
@@ -568,7 +568,9 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         if (shift > kFreshFeedbackPx) t->camera_moving = true;                 // hysteresis: frames that alternate between the two
         else if (shift < 0.5f * kFreshFeedbackPx) t->camera_moving = false;    // modes get the worst of both
     }
-    const bool fresh = t->camera_moving;
+    // (one more frame after the motion stops: the frame before last still shows the old view, the last one the new)
+    const bool fresh = t->camera_moving || t->was_moving;
+    t->was_moving = t->camera_moving;
     const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
