@@ -107,7 +107,7 @@ struct vf_terrain {
         uint2 *work = nullptr;           // busy tiles of the frame: (item, weight), heaviest first
         uint32_t *work_count = nullptr;  // [0] work items, [1] split budget used, [2] queue head, [3] items handed to the complete tile kernel
         uint32_t *redo = nullptr;        // those items (indices into work)
-        uint32_t *background = nullptr;  // per local tile: 1 = no block row reaches it
+        uint32_t *background = nullptr;  // per local tile: bit 0 = no block row reaches it; bits 8.. = log2 of the strips it is cut into
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later (+ [ntiles] = split quantum)
         hipEvent_t planned = nullptr, drawn = nullptr;
     } ps[2];
@@ -294,6 +294,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
         A((void **)&S.background, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles + 1) * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemset(S.background, 0, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
     }
@@ -417,7 +418,10 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->rendered = false;
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipStreamSynchronize(t->side));
-    for (auto &S : t->ps) VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    for (auto &S : t->ps) {
+        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+        VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
+    }
     return VF_OK;
 }
 
@@ -455,7 +459,10 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
     t->rendered = false;
     VF_HIP_TRY(hipStreamSynchronize(t->side));
-    for (auto &S : t->ps) VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+    for (auto &S : t->ps) {
+        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+        VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
+    }
     return VF_OK;
 }
 
@@ -597,7 +604,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         if (fresh) VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));   // (the block boxes above did not need to wait)
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
-                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u);
+                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));

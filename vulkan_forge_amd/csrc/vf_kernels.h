@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                                               uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                               const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
-                                              const uint32_t *__restrict__ rc_hi, uint32_t moving)
+                                              const uint32_t *__restrict__ rc_hi, uint32_t moving, const uint32_t *last_flags)
 {
     __shared__ uint32_t s_hits;
     int32_t px_lo, px_hi, py_lo, py_hi;
@@ -656,8 +656,19 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     const uint32_t total = s_hits;
     if (total) {
         if (threadIdx.x == 0) {
-            background[blockIdx.x] = 0u;
-            uint32_t seen = last_blocks[blockIdx.x];
+            // A tile's time is the sum over its strips, and strips repeat block work: cut in 16 it reports about twice what it
+            // would whole.  Taken at face value that keeps a tile cut that was cut once -- the plan has several fixed points, and
+            // which one a handle sits in depends on its history (1920 x 1080, grid 2048: 0.50 ms per frame from a cold start, 0.56
+            // for good after five frames of another view).  So an unsharded handle brings the time back to "as one item" first:
+            // / (1 + log2(strips) / 4), strips as recorded in the flags word of the frame the time comes from (one fixed point:
+            // 0.52 ms whatever came before).  Shards keep the face value: their cold-start fixed point is the better one for a
+            // GPU with few tiles (emulated 2 / 4 ranks: 0.74 / 0.52 ms against 0.84 / 0.55), and their camera rarely moves.
+            const bool as_one = P.nranks == 1u && !P.shard_tiles;
+            auto tile_time = [&](uint32_t idx) -> uint32_t {
+                const uint32_t t = last_blocks[idx];
+                return as_one ? (uint32_t)(((unsigned long long)t * 4ull) / (4ull + (last_flags[idx] >> 8))) : t;
+            };
+            uint32_t seen = tile_time(blockIdx.x);
             const uint32_t mean = *last_mean;
             if ((seen == 0u || moving) && mean && P.nranks == 1u && !P.shard_tiles) {
                 // The camera moved.  A tile that is busy now but was background in the frame the feedback comes from would sort last
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                 for (int32_t dy = -reach; dy <= reach; ++dy)
                     for (int32_t dx = -reach; dx <= reach; ++dx) {
                         const int32_t x = tx + dx, y = ty + dy;
-                        if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, last_blocks[(uint32_t)y * P.ntx + (uint32_t)x]);
+                        if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, tile_time((uint32_t)y * P.ntx + (uint32_t)x));
                     }
             }
             const uint32_t weight = seen ? seen : total;
@@ -684,6 +695,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                 // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer strips
                 while (lg && atomicAdd(split_budget, (1u << lg) - 1u) + (1u << lg) - 1u > kSplitBudget) { atomicSub(split_budget, (1u << lg) - 1u); --lg; }
             }
+            background[blockIdx.x] = lg << 8;               // busy; the strips it is cut into (read back with its time, above)
             const uint32_t parts = 1u << lg;
             const uint32_t at = atomicAdd(work_count, parts);
             for (uint32_t p = 0; p < parts; ++p) work[at + p] = make_uint2(blockIdx.x | (p << 20) | (lg << 24), weight >> lg);
@@ -700,7 +712,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
 __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__restrict__ background, uint32_t *__restrict__ rgba,
                                                uint32_t *__restrict__ vis_out)
 {
-    if (background[blockIdx.x] == 0u) return;
+    if ((background[blockIdx.x] & 1u) == 0u) return;
     int32_t px_lo, px_hi, py_lo, py_hi;
     const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
     const int32_t w = px_hi - px_lo + 1, h = py_hi - py_lo + 1;
