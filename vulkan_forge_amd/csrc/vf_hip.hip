@@ -87,6 +87,7 @@ struct vf_terrain {
     bool have_uniforms = false;
     float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
     bool have_drawn = false, camera_moving = false, was_moving = false;
+    uint32_t frames_since_reset = 0;     // frames planned since create / set_shard (the feedback arrays were cleared then)
     // device state
     float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
     int32_t *d_txi = nullptr, *d_tyj = nullptr;
@@ -416,6 +417,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
     t->local_tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
     t->rendered = false;
+    t->frames_since_reset = 0;
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipStreamSynchronize(t->side));
     for (auto &S : t->ps) {
@@ -458,6 +460,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->rank = rank; t->nranks = nranks; t->skew = skew;
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
     t->rendered = false;
+    t->frames_since_reset = 0;
     VF_HIP_TRY(hipStreamSynchronize(t->side));
     for (auto &S : t->ps) {
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
@@ -576,7 +579,9 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         else if (shift < 0.5f * kFreshFeedbackPx) t->camera_moving = false;    // modes get the worst of both
     }
     // (one more frame after the motion stops: the frame before last still shows the old view, the last one the new)
-    const bool fresh = t->camera_moving || t->was_moving;
+    // ... and the second frame of a handle: its own plan state has no times yet, the first frame's has
+    const bool fresh = t->camera_moving || t->was_moving || t->frames_since_reset == 1;
+    t->frames_since_reset++;
     t->was_moving = t->camera_moving;
     const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
@@ -596,16 +601,22 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[0], side));
     const size_t rc_n = (size_t)t->nb * t->ntx;
     uint32_t *rc_lo = S.rc, *rc_hi = S.rc + rc_n;
-    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi);
+    // the split quantum comes from the same tile times the plan will read: summed by an extra workgroup of k_block_boxes, or --
+    // when those times belong to the frame still being drawn -- by a kernel of its own after the wait below
+    uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
+    hipLaunchKernelGGL(k_block_boxes, dim3(t->nb + 1), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi,
+                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum);
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
         VF_HIP_TRY(hipMemsetAsync(S.work_count, 0, 4 * sizeof(uint32_t), side));
-        uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
-        if (fresh) VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));   // (the block boxes above did not need to wait)
+        if (fresh) {
+            VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));         // (the block boxes above did not need to wait)
+            hipLaunchKernelGGL(k_quantum, dim3(1), dim3(512), 0, side, O.feedback, t->ntx * t->nty, quantum);
+        }
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
-                           F.feedback, F.feedback + (size_t)t->ntx * t->nty, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
-        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty, quantum);
+                           F.feedback, quantum, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));

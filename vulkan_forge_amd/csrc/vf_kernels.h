@@ -84,11 +84,37 @@ __global__ __launch_bounds__(64) void k_height_blocks(uint32_t n, uint32_t nb, u
 // the projected bottom / top faces, so the whole block lies within `rad` of the segment joining the two face centres
 // (rad = largest centre-to-corner distance + 1 px).  For oblique views the streak a block sweeps is long and thin
 // and the capsule rejects most of the tiles its bounding box crosses.
+// Split quantum of a frame: VF_SPLIT_QUANTUM_X4 quarter-shares of the time the tiles took in the frame whose feedback steers this
+// one (sum over its tiles / kTargetItems); 0 = no feedback yet, nothing is split.  One workgroup.
+constexpr uint32_t kTargetItems = 1024;                    // work items that keep 256 CUs busy (4 per CU)
+__device__ __forceinline__ void publish_quantum(const uint32_t *__restrict__ feedback, uint32_t ntiles, uint32_t *__restrict__ quantum)
+{
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0ull;
+    __syncthreads();
+    unsigned long long sum = 0;
+    for (uint32_t k = threadIdx.x; k < ntiles; k += blockDim.x) sum += feedback[k];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&s_sum, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) *quantum = s_sum ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X4 * s_sum / (4ull * kTargetItems)) : 0u;
+}
+__global__ __launch_bounds__(512) void k_quantum(const uint32_t *__restrict__ feedback, uint32_t ntiles, uint32_t *__restrict__ quantum)
+{
+    publish_quantum(feedback, ntiles, quantum);
+}
+
+// One workgroup per block row, plus one (index nb) that publishes the frame's split quantum when `feedback` is given.
 __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2 *__restrict__ bounds,
                                                      PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes,
                                                      float4 *__restrict__ cap_seg, float *__restrict__ cap_rad,
-                                                     uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi)
+                                                     uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi,
+                                                     const uint32_t *__restrict__ feedback, uint32_t ntiles_all, uint32_t *__restrict__ quantum)
 {
+    if (blockIdx.x == P.nb) {                               // (uniform per workgroup)
+        if (feedback) publish_quantum(feedback, ntiles_all, quantum);
+        return;
+    }
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
     __shared__ uint32_t s_lo[kMaxTileCols], s_hi[kMaxTileCols];   // this block row's [first, last+1) block per tile column
     const uint32_t by = blockIdx.x;
@@ -619,7 +645,6 @@ __device__ __forceinline__ TilePlace tile_rect(const FrameParams &P, uint32_t ti
 // work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2, 4, 8 or 16 column strips, each its own
 // workgroup (blocks are only a few pixels wide, so narrow strips share little work)
 constexpr uint32_t kSplitBudget = 2048;                    // extra work items a frame may create by splitting
-constexpr uint32_t kTargetItems = 1024;                    // work items that keep 256 CUs busy (4 per CU)
 __device__ __forceinline__ uint32_t work_tile(uint32_t code) { return code & 0xFFFFFu; }
 __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_t &px_hi)
 {
@@ -736,28 +761,14 @@ __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__
 }
 
 // single workgroup: order the work items by descending weight (bitonic sort in LDS over the next power of two; lists
-// longer than 4096 are sorted in independent 4096-item runs, which is all the scheduler needs), publish the mean
-// block count per busy tile for the next frame's split decision, and clear the per-tile feedback counters.
+// longer than 4096 are sorted in independent 4096-item runs, which is all the scheduler needs) and clear this plan state's
+// per-tile feedback counters (the plan has read them).
 __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
-                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles, uint32_t *__restrict__ last_mean)
+                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles)
 {
     __shared__ uint2 s[4096];
-    __shared__ unsigned long long s_sum;
-    __shared__ uint32_t s_busy;
     const uint32_t n = *work_count;
-    if (threadIdx.x == 0) { s_sum = 0ull; s_busy = 0u; }
-    __syncthreads();
-    // mean of last frame's block counts over the tiles that had any (before they are overwritten by this frame)
-    {
-        unsigned long long sum = 0; uint32_t busy = 0;
-        for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) { const uint32_t b = last_blocks[k]; sum += b; busy += b ? 1u : 0u; }
-        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); busy += __shfl_xor(busy, o); }
-        if ((threadIdx.x & 63u) == 0) { atomicAdd(&s_sum, sum); atomicAdd(&s_busy, busy); }
-    }
-    __syncthreads();
-    // split quantum: half of 4x the even share (a tile reaching 2 quanta is cut in two, 4 quanta in four, ...)
-    if (threadIdx.x == 0) *last_mean = s_busy ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X4 * s_sum / (4ull * kTargetItems)) : 0u;
-    for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // k_tile adds this frame's counts
+    for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // this frame's tile kernel adds its times
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
         uint32_t cap = 2;
