@@ -2,27 +2,37 @@
 """bench.py -- BASELINE.json's metric on BASELINE.json's config.
 
   metric   Mpix/s terrain shade: W*H*frames / wall time, RGBA8 complete in HBM (rank 0 holds the gathered frame)
-  workload C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
+  workload c4 (default): C4 of SURVEY.md 8(d): Scene 4096x4096, grid=4096, 4096x4096 R32F heightmap
            (np.random.default_rng(20250816).random(float32)*0.5-0.25), default camera eye (3,2,3), viridis.
-           A "step" = one frame: k_block_boxes + k_plan + k_plan_sort (on the handle's side stream: they only touch plan state and
-           overlap the previous frame's tile kernel) + k_clear + k_tile (+ gather to rank 0 + stitch when N > 1).
-  N > 1    one process per GPU (torch.distributed, backend nccl = RCCL): screen-tile split -- 64x64 tile (tx, ty)
+           A "step" = one frame: k_block_boxes + k_block_setup + k_plan + k_plan_sort (on the handle's side stream: they only
+           touch plan state and overlap the previous frame's tile kernel) + k_clear + k_tile (+ gather to rank 0 + stitch
+           when N > 1).
+           c5: BASELINE config 5 -- 64 camera poses on the default camera's orbit over one grid=2048 terrain, 1920x1080
+           (SURVEY.md 8(d)); a "step" = every rank renders its next pose (rank r takes poses k = r mod N; replicas, no
+           collective, as python/tools/determinism_harness.py:39-62 runs independent renders).
+  N > 1    one process per GPU (torch.distributed, backend nccl = RCCL).  c4: screen-tile split -- 64x64 tile (tx, ty)
            belongs to rank (tx + skew*ty) % N; every rank renders only its tiles into a tile-major slab, the slabs go to
-           rank 0 point-to-point over xGMI (vulkan_forge_amd/dist.py::TileExchange) and vf_stitch_tiles_device writes the
+           rank 0 point-to-point over xGMI (vulkan_forge_amd/dist.py::TileExchange; --cabi-gather: the library's own
+           vf_dist_gather_tiles on an RCCL communicator made through the C-ABI) and vf_stitch_tiles_device writes the
            frame.  The exchange is double-buffered: frame k travels while frame k+1 renders; every one of the K timed
            frames is rendered, gathered and stitched inside the timed region (--serial: no overlap).  Total work is fixed,
            so scaling is "strong".
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...          (no launcher needed: spawns python -m torch.distributed.run itself, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (fields: see the driver contract; plus "roofline" and "cpu_baseline").
+Prints ONE JSON line on rank 0 (fields: see the driver contract; plus "roofline", "roofline_fragment" and "cpu_baseline").
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed())
 
 
 def parse():
@@ -37,28 +48,41 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=4096, help="frame width = height")
-    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--workload", choices=["c4", "c5"], default="c4")
+    ap.add_argument("--size", type=int, default=4096, help="c4: frame width = height")
+    ap.add_argument("--grid", type=int, default=None, help="default: 4096 (c4), 2048 (c5)")
     ap.add_argument("--camera", choices=["default", "fill"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (fill camera) measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other camera, fragment stage, cold frame)")
     ap.add_argument("--check", action="store_true", help="after timing, compare the gathered frame with a single-rank render")
     ap.add_argument("--serial", action="store_true", help="N>1: finish each frame's exchange before rendering the next (no overlap)")
+    ap.add_argument("--cabi-gather", action="store_true",
+                    help="N>1: exchange through the library's own RCCL entry points (vf_dist_comm_init / vf_dist_gather_tiles) "
+                         "instead of torch.distributed's point-to-point calls")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
                          "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
     return ap.parse_args()
 
 
-def camera_uniforms(name, W, H):
+def spawn_ranks(n):
+    """--gpus N > 1 without a launcher: start N fresh rank processes and relay what rank 0 prints.  Decided before torch.cuda,
+    the HIP library or a process group exist in this process -- it never touches the GPU and only waits for its children."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def look_at_uniforms(W, H, eye, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy=45.0):
     """Uniform block through the product's own host code (the drop-in module), not the oracle."""
-    import vulkan_forge_amd as vf
     import numpy as np
-    view = vf.camera_look_at((3.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
-    proj = vf.camera_perspective(45.0, W / H, 0.1, 100.0, "wgpu")
-    if name == "fill":                                           # SURVEY.md 8(d) C4(b): frame-filling top-down camera
-        view = vf.camera_look_at((0.0, 2.2, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0))
-        proj = vf.camera_perspective(60.0, W / H, 0.1, 100.0, "wgpu")
+    import vulkan_forge_amd as vf
+    view = vf.camera_look_at(eye, target, up)
+    proj = vf.camera_perspective(fovy, W / H, 0.1, 100.0, "wgpu")
     u = np.zeros(44, np.float32)
     u[:16] = view.T.reshape(-1)                                   # column-major
     u[16:32] = proj.T.reshape(-1)
@@ -69,8 +93,55 @@ def camera_uniforms(name, W, H):
     return u
 
 
+def camera_uniforms(name, W, H):
+    if name == "fill":                                           # frame-filling top-down camera
+        return look_at_uniforms(W, H, (0.0, 2.2, 0.0), up=(0.0, 0.0, -1.0), fovy=60.0)
+    return look_at_uniforms(W, H, (3.0, 2.0, 3.0))
+
+
+def orbit_uniforms(k, W, H, nposes=64):
+    """C5 pose k: eye on the default camera's orbit, theta_k = 2 pi k / 64; k = 8 is the default eye (3,2,3)."""
+    th = 2.0 * math.pi * k / nposes
+    return look_at_uniforms(W, H, (3.0 * math.sqrt(2.0) * math.cos(th), 2.0, 3.0 * math.sqrt(2.0) * math.sin(th)))
+
+
+def host_cpus():
+    """(os.cpu_count(), CPUs this process may run on, cgroup CPU quota or None, model name)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, aff, quota, model
+
+
+def lib_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                         # (nothing above imported torch or loaded the HIP library)
+
     import numpy as np
     import torch                                                  # first: the HIP runtime it bundles is the one shared below
     import torch.distributed as dist
@@ -80,9 +151,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible", file=sys.stderr)
         sys.exit(1)
@@ -96,24 +166,30 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    import vulkan_forge_amd as vf
     from vulkan_forge_amd import cabi, dist as vdist
 
-    W = H = args.size
-    G = args.grid
-    lut = np.load(os.path.join(ROOT, "tests", "golden", "colormaps_rgba8.npz"))["viridis"]
-    rng = np.random.default_rng(20250816)
+    c5 = args.workload == "c5"
+    W, H = (1920, 1080) if c5 else (args.size, args.size)
+    G = args.grid or (2048 if c5 else 4096)
+    lut = vf.colormap_rgba8("viridis")                            # the product's registry (src/colormap/mod.rs), not a test fixture
+    rng = np.random.default_rng(20250817 if c5 else 20250816)
     height_host = rng.random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
     d_height = torch.from_numpy(height_host).to(dev)              # inputs resident in HBM before the timed region
 
-    t = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)
-    t.set_height_device(d_height.data_ptr(), G, G)
+    def new_handle():
+        h = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)
+        h.set_height_device(d_height.data_ptr(), G, G)
+        return h
+
+    t = new_handle()
     stream = torch.cuda.current_stream().cuda_stream
-    image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if (rank == 0 or c5) else None
     depth = 1 if args.serial else 2
-    if world == 1:
-        t.set_output_device(image.data_ptr())                    # N=1: render straight into the frame
-        share = 1.0
-        ex = None
+    share = 1.0
+    ex = comm = None
+    if world == 1 or c5:
+        t.set_output_device(image.data_ptr())                    # whole frames: render straight into the frame
     else:
         # rehearsal: same exchange code over gloo through host memory (the device slabs are copied out and back in)
         ex = vdist.TileExchange(W, H, "cpu" if args.rehearse else dev, depth=depth)
@@ -123,20 +199,36 @@ def main():
         if args.rehearse:
             dev_local = torch.zeros(ex.stride * vdist.TILE_WORDS, dtype=torch.int32, device=dev)
             dev_gathered = torch.zeros((world, ex.stride * vdist.TILE_WORDS), dtype=torch.int32, device=dev) if rank == 0 else None
+        if args.cabi_gather and not args.rehearse:
+            # an RCCL communicator of the library's own (vf_dist_comm_init); the 128-byte id travels over the host-side group
+            uid = [t.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = t.dist_comm_init(uid[0], rank, world)
     frame_no = [0]
 
     def finish(slot):
         """complete the exchange that last used `slot`; rank 0 writes that frame"""
+        if comm is not None:                                         # RCCL calls were queued on `stream`: already ordered
+            if rank == 0 and ex.pending_frame[slot]:
+                t.stitch_tiles(ex.gathered[slot].data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, stream)
+            ex.pending_frame[slot] = False
+            return
         g = ex.finish(slot)
         if rank == 0 and g is not None and ex.pending_frame[slot]:
             if args.rehearse:
                 dev_gathered.copy_(g)
                 g = dev_gathered
             t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, stream)
-        if ex is not None:
-            ex.pending_frame[slot] = False
+        ex.pending_frame[slot] = False
+
+    pose = [rank]
 
     def step():
+        if c5:                                                       # replicas: this rank's next pose, no exchange
+            t.set_uniforms(orbit_uniforms(pose[0] % 64, W, H))
+            pose[0] += world
+            t.render(stream)
+            return
         if world == 1:
             t.render(stream)
             return
@@ -146,16 +238,19 @@ def main():
         out = dev_local if args.rehearse else ex.output(slot)
         t.set_output_device(out.data_ptr())
         t.render(stream)
-        if args.rehearse:
-            torch.cuda.synchronize()
-            ex.output(slot).copy_(out)
-        ex.start(slot)
+        if comm is not None:
+            t.dist_gather_tiles(comm, 0, ex.gathered[slot].data_ptr() if rank == 0 else 0, ex.stride, stream)
+        else:
+            if args.rehearse:
+                torch.cuda.synchronize()
+                ex.output(slot).copy_(out)
+            ex.start(slot)
         ex.pending_frame[slot] = True
         if args.serial:
             finish(slot)
 
     def flush():
-        if world > 1:
+        if ex is not None:
             for k in range(depth):
                 finish((frame_no[0] + k) % depth)                    # oldest first
 
@@ -163,14 +258,20 @@ def main():
         ex.pending_frame = [False] * depth
 
     exchanged = [False]
-    SETTLE = 16  # set-up, not steps: the frame plan is feedback-driven (last frame's per-tile cost decides order and strip
-                 # splitting; two frames old, because frames overlap) and needs a few frames of a new camera to converge; results never depend on it
+    # SETTLE untimed frames are set-up, not steps: the frame plan is feedback-driven (a frame's per-tile times decide order and
+    # strip splitting two frames later, because frames overlap) and needs a few frames of a new camera to converge; results
+    # never depend on it.  The JSON reports `settle_frames` and what a frame without feedback costs (`cold_frame_ms`).
 
     def timed(camera, steps, warmup):
-        t.set_uniforms(camera_uniforms(camera, W, H))
-        for _ in range(SETTLE):
-            t.render(stream)
-        if world > 1 and not exchanged[0]:
+        if not c5:
+            t.set_uniforms(camera_uniforms(camera, W, H))
+            for _ in range(SETTLE):
+                t.render(stream)
+        else:
+            for _ in range(SETTLE):                                  # the orbit itself: settle on the poses before the first timed one
+                step()
+            pose[0] = rank
+        if ex is not None and not exchanged[0]:
             # set-up, not steps: the first exchange creates the point-to-point channels (RCCL opens them lazily, about a second);
             # like communicator creation it must not land in the timed region when the caller asks for --warmup 0
             for _ in range(depth):
@@ -202,17 +303,18 @@ def main():
 
     dt, tm = timed(args.camera, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
-    value = W * H * args.steps / dt / 1e6
+    frames = args.steps * (world if c5 else 1)
+    value = W * H * frames / dt / 1e6
 
     extra = None
-    if not args.no_extra:
+    if not args.no_extra and not c5:
         other = "fill" if args.camera == "default" else "default"
-        dt2, tm2 = timed(other, max(3, args.steps // 4), 1)
         n2 = max(3, args.steps // 4)
+        dt2, tm2 = timed(other, n2, 1)
         extra = {"camera": other, "value": W * H * n2 / dt2 / 1e6, "ms_per_step": dt2 / n2 * 1e3, "tile_kernel_ms": tm2["tile_ms"]}
 
     check = None
-    if args.check:
+    if args.check and not c5:
         t.set_uniforms(camera_uniforms(args.camera, W, H))
         step()
         flush()
@@ -221,8 +323,7 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             got = image.clone()
-            single = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)   # unsharded handle, same inputs
-            single.set_height_device(d_height.data_ptr(), G, G)
+            single = new_handle()                                    # unsharded handle, same inputs
             single.set_uniforms(camera_uniforms(args.camera, W, H))
             single.set_output_device(image.data_ptr())
             single.render(stream)
@@ -232,64 +333,142 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # ---- roofline of the dominant kernel (k_tile: vertex + setup + raster + fragment, fused) -------------------
+    # ---- secondary measurements on one GPU: the fragment stage on its own, a frame without scheduling feedback --------------
+    frag = cold = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        probe = new_handle()
+        cams = [("pose8", orbit_uniforms(8, W, H))] if c5 else [(c, camera_uniforms(c, W, H)) for c in ("default", "fill")]
+        frag = {}
+        for name, u in cams:
+            probe.set_uniforms(u)
+            probe.render(stream)
+            torch.cuda.synchronize()
+            ft = probe.fragment_stage(repeats=10)
+            # SURVEY.md 8(d) B_frag: visibility read + RGBA8 written for every pixel + every height texel at most once;
+            # "covered": only what the visible primitives need (12 B per covered pixel + the LUT), the rest is clear colour
+            b_frag = 4 * W * H + 4 * W * H + 4 * G * G
+            b_cov = 12 * ft["covered_pixels"] + 1024
+            s = ft["resolve_ms"] * 1e-3
+            frag[name] = {"ms": ft["resolve_ms"], "covered_pixels": ft["covered_pixels"], "bytes": b_frag,
+                          "GB/s": b_frag / s / 1e9, "frac": b_frag / s / 1e9 / HBM_PEAK_GBPS,
+                          "bytes_covered_only": b_cov, "frac_covered_only": b_cov / s / 1e9 / HBM_PEAK_GBPS,
+                          "equals_tile_kernel_output": bool(ft["equal_to_frame"])}
+        probe.close()
+        # first frames of a fresh handle: no feedback yet (unsplit items); includes the height-cache build on the very first
+        fresh = new_handle()
+        fresh.set_uniforms(cams[0][1])
+        fresh.set_output_device(image.data_ptr())
+        torch.cuda.synchronize()
+        cold = []
+        for _ in range(3):
+            c0 = time.perf_counter()
+            fresh.render(stream)
+            torch.cuda.synchronize()
+            cold.append((time.perf_counter() - c0) * 1e3)
+        fresh.close()
+
+    # ---- roofline of the dominant kernel (k_tile: set-up + raster + fragment, fused) --------------------------------------
     # algorithmic bytes per launch (whole frame): height texture read once + RGBA8 written once + LUT
-    algo_bytes = 4 * G * G + 4 * W * H + 1024
     kernel_s = tm["tile_ms"] * 1e-3                               # `share` = this rank's share of the frame's pixels
     rank_bytes = int(4 * G * G + 4 * W * H * share + 1024)
     achieved = rank_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic, sq = None, None
+    # SQ / TCC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command):
+    # they come from profiles/pmc_traffic.json and count only when that file was collected on the library loaded here
+    lib_hash = lib_sha256(cabi.DEFAULT_LIB)
+    traffic = sq = None
+    source = None
+    stale = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = f"{W}x{H}_g{G}_{'orbit' if c5 else args.camera}_n{world}"
     if os.path.exists(pmc_path):
         try:
-            pm = json.load(open(pmc_path))
-            key = f"{W}x{H}_g{G}_{args.camera}_n{world}"
-            if key in pm:
-                traffic = pm[key]["hbm_bytes_per_launch"]
-                sq = pm[key].get("sq")
+            pm = json.load(open(pmc_path)).get(key)
         except Exception:  # noqa: BLE001
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_clear + k_tile (the kernels on the caller's stream: they produce the frame)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": rank_bytes, "kernel_ms": tm["tile_ms"],
-                "plan_on_side_stream_elapsed_ms": {"k_block_boxes": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]}, "frames_averaged": tm["frames"], "rank_share_of_frame": share}
-    if sq:   # the path has no contraction and is not HBM-bound: what it IS bound by, from the committed SQ counter passes
-        roofline["valu_busy_frac"] = sq["valu_busy_frac"]
-        roofline["active_lanes_per_valu_inst"] = sq["active_lanes_per_valu_inst"]
+            pm = None
+        if pm:
+            source = f"profiles/pmc_traffic.json@{pm.get('tag', '?')}"
+            stale = pm.get("lib_sha256") != lib_hash
+            if not stale:
+                traffic = pm["hbm_bytes_per_launch"]
+                sq = pm.get("sq")
+    roofline = {"bound": "valu",
+                "kernel": "k_clear + k_tile (the kernels on the caller's stream: they produce the frame)",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "hbm_frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_stale": stale, "counters_source": source,
+                "lib_sha256": lib_hash, "algorithmic_bytes_per_launch": rank_bytes, "kernel_ms": tm["tile_ms"],
+                "plan_on_side_stream_elapsed_ms": {"k_block_boxes+k_block_setup": tm["ranges_ms"], "k_plan+k_plan_sort": tm["plan_ms"]},
+                "frames_averaged": tm["frames"], "rank_share_of_frame": share,
+                "note": "the path has no contraction and is not HBM-bound: the tile kernel is bound by vector-ALU issue "
+                        "(valu_issue_frac of the SIMDs' issue slots, lane_efficiency of 64 lanes active per instruction); "
+                        "frac / hbm_frac is the algorithmic-bytes figure the contract asks for"}
+    if sq:
+        roofline["valu_issue_frac"] = sq["valu_busy_frac"]
+        roofline["lane_efficiency"] = sq["active_lanes_per_valu_inst"] / 64.0
+        roofline["valu_lane_throughput_frac"] = sq["valu_busy_frac"] * sq["active_lanes_per_valu_inst"] / 64.0
+        roofline["valu_wave_insts_per_frame"] = sq.get("valu_wave_insts")
 
     # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
-        threads = max(1, min(os.cpu_count() or 1, 16))
-        u = camera_uniforms(args.camera, W, H)
+        ncpu, aff, quota, model = host_cpus()
+        threads = max(1, min(aff, int(quota) if quota and quota >= 1 else aff, oracle.max_threads()))
+        u = orbit_uniforms(8, W, H) if c5 else camera_uniforms(args.camera, W, H)
         c0 = time.perf_counter()
         oracle.render_terrain(u, W, H, G, height_host, lut, nthreads=threads, want_vis=False)
         cdt = time.perf_counter() - c0
+        # one thread: a bounded sample -- the rows of every 8th 64-row band (1/8 of the frame's pixels; every primitive is
+        # still transformed and set up, only rows outside the sample are skipped)
+        nb = 8 if H >= 8 * 64 else 1
+        rows = sum(min(64, H - b * 64) for b in range((H + 63) // 64) if b % nb == 0)
+        c0 = time.perf_counter()
+        oracle.render_terrain(u, W, H, G, height_host, lut, rank=0, nranks=nb, band_h=64, nthreads=1, want_vis=False)
+        sdt = time.perf_counter() - c0
         cpu = {"value": W * H / cdt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
-               "sample": f"1 full frame of the same workload ({W}x{H}, grid {G}, {args.camera} camera) in {cdt:.2f} s, "
-                         f"oracle/vf_oracle.c gcc -O2 OpenMP; the reference's wgpu software-adapter path cannot be built in this image"}
+               "single_thread": {"value": W * rows / sdt / 1e6, "unit": "Mpix/s", "cores": 1,
+                                 "sample": f"rows of every {nb}th 64-row band ({rows} of {H} rows; all primitives set up) in {sdt:.2f} s"},
+               "host": {"nproc": ncpu, "affinity": aff, "cgroup_cpu_quota": quota, "cpu_model": model},
+               "sample": f"1 full frame of the same workload ({W}x{H}, grid {G}, {'pose 8' if c5 else args.camera + ' camera'}) in {cdt:.2f} s on "
+                         f"{threads} threads (every CPU this process may use), oracle/vf_oracle.c gcc -O2 OpenMP; the reference's wgpu "
+                         f"software-adapter path cannot be built in this image"}
 
     if rank == 0:
+        if c5:
+            metric = f"Mpix/s terrain shade (grid={G}, {W}x{H}, 64-pose orbit batch)"
+            workload = (f"C5: 64 camera look-ats on the default camera's orbit over one grid={G} terrain, Scene {W}x{H}, R32F {G}x{G} "
+                        f"heightmap rng(20250817)*0.5-0.25, viridis; rank r renders poses k = r mod N back to back on one handle")
+            par = "1 GPU, poses in order" if world == 1 else f"pose-parallel replicas over {world} GPUs, no collective"
+        else:
+            metric = "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})"
+            workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
+            par = ("1 GPU, whole frame" if world == 1 else
+                   f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), p2p gather to rank 0 "
+                   f"({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, "
+                   f"{'serial' if args.serial else 'double-buffered'}")
         out = {
-            "metric": "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})",
-            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": metric, "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "replicas" if c5 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis",
-                       "width": W, "height": H, "grid": G, "camera": args.camera,
-                       "parallelism": "1 GPU, whole frame" if world == 1 else
-                                      f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), p2p gather to rank 0 (RCCL) "
-                                      f"+ stitch, {'serial' if args.serial else 'double-buffered'}"},
+            "config": {"workload": workload, "width": W, "height": H, "grid": G, "camera": "orbit" if c5 else args.camera, "parallelism": par},
+            "settle_frames": SETTLE,
             "roofline": roofline,
+            "roofline_fragment": frag,
             "cpu_baseline": cpu,
             "other_camera": extra,
         }
+        if c5:
+            out["ms_per_pose"] = dt / args.steps * 1e3               # per rank: one pose per step
+        if cold:
+            out["cold_frame_ms"] = cold[0]
+            out["cold_frames_ms"] = {"first (builds the height cache, no feedback)": cold[0], "second (first frame's feedback)": cold[1], "third": cold[2]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
         if args.rehearse:
             out["rehearsal"] = "gloo via host memory on one GPU; not a performance number"
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        t.dist_comm_destroy(comm)
     t.close()
     if world > 1:
         dist.barrier()

@@ -62,6 +62,7 @@ typedef struct vf_timings {
     uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out) */
     uint32_t tiles;             /* workgroups launched = owned screen tiles */
     uint32_t frames;            /* frames averaged */
+    uint32_t blocks_distinct;   /* distinct grid blocks behind blocks_rasterised in the last frame (of grid blocks in total: ceil((n-1)/8)^2) */
 } vf_timings;
 
 const char *vf_last_error(void);
@@ -210,6 +211,48 @@ int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
 /* Same for tile shards: gather buffer [nranks][stride_tiles][64][64][4] (stride_tiles >= the largest shard) -> (H,W,4). */
 int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width, uint32_t height,
                            uint32_t nranks, uint32_t skew, uint32_t stride_tiles, void *stream);
+
+/* ---- multi-GPU exchange over RCCL (new: the reference creates one device per object,
+ * src/terrain/mod.rs:277-294, and has no exchange) -------------------------------------------------------------
+ * One process per GPU.  The library resolves RCCL at run time (librccl.so.1: the copy already loaded in the process,
+ * e.g. PyTorch's, else the ROCm one); nothing here needs torch.  A communicator is an `ncclComm_t` passed as void*:
+ * either one the host already owns (torch.distributed's, a Rust host's own binding) or one made by vf_dist_comm_init.
+ *
+ *   rank 0:  vf_dist_unique_id(id)            -> hand the 128 bytes to every rank (any host channel)
+ *   all:     vf_dist_comm_init(ctx, id, rank, nranks, &comm)
+ *   frame:   vf_terrain_set_tile_shard(t, rank, nranks, skew); vf_terrain_set_output_device(t, slab); vf_terrain_render(t, s);
+ *            vf_dist_gather_tiles(t, comm, 0, gathered, stride_tiles, s);      (all ranks; `gathered` used on the root)
+ *            root: vf_stitch_tiles_device(ctx, gathered, image, W, H, nranks, skew, stride_tiles, s);
+ */
+#define VF_DIST_UNIQUE_ID_BYTES 128
+int vf_dist_available(void);                                   /* 1 when RCCL could be resolved in this process */
+int vf_dist_unique_id(uint8_t id[VF_DIST_UNIQUE_ID_BYTES]);    /* ncclGetUniqueId */
+int vf_dist_comm_init(vf_ctx *ctx, const uint8_t id[VF_DIST_UNIQUE_ID_BYTES], int rank, int nranks, void **comm);   /* ncclCommInitRank on ctx's device */
+void vf_dist_comm_destroy(void *comm);
+/* Tile shards -> rank `root`, point to point (every sender on its own xGMI link to the root, no ring): one
+ * ncclGroupStart / ncclSend | ncclRecv x (nranks - 1) / ncclGroupEnd on `stream`, ordered after the render queued there.
+ * The handle must be tile-sharded (vf_terrain_set_tile_shard); it sends exactly its local tiles (local_tiles * 16384
+ * bytes) from its current output buffer.  On the root `dev_gathered` is [nranks][stride_tiles][64][64][4]: rank r's slab lands in
+ * slot r; the root's own slab is not moved when it rendered straight into slot `root` (vf_terrain_set_output_device), and
+ * goes through RCCL to itself otherwise.  `dev_gathered` is ignored on the other ranks. */
+int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gathered, uint32_t stride_tiles, void *stream);
+/* Band shards (vf_terrain_set_shard) -> rank `root`: every band is a contiguous band_h * W * 4-byte slab of the final image,
+ * so the root receives each remote band in place in `dev_image` ((H, W, 4), no stitch pass) and copies its own. */
+int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream);
+
+/* ---- diagnostics: the fragment stage on its own (BASELINE.json north_star names it) ----------------------------
+ * Renders the current uniforms once with the visibility store enabled (into scratch buffers: the handle's output, feedback
+ * and timing state stay as they were), then runs `repeats` launches of the resolve kernel -- visibility (H, W) u32 ->
+ * RGBA8 through fs_main + sRGB store (src/shaders/terrain.wgsl:69-91), the same device code the tile kernel runs on its
+ * LDS tile -- and reports the average launch time (HIP events) and the number of covered pixels.  Whole-frame handles only.
+ * Algorithmic bytes of a launch: 4 W H (visibility) + 4 W H (RGBA8) + 4 Tw Th (heights). */
+typedef struct vf_fragment_timing {
+    float resolve_ms;        /* average of `repeats` launches */
+    uint32_t covered_pixels; /* pixels with a visible primitive */
+    uint32_t repeats;
+    uint32_t equal_to_frame; /* 1 when the resolved RGBA8 equals the frame the tile kernel produced, byte for byte */
+} vf_fragment_timing;
+int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment_timing *out);
 
 #ifdef __cplusplus
 }

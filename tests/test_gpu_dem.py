@@ -82,7 +82,10 @@ def test_argument_errors():
     for args, msg in ((((hm, (0.0, 1.0), 1.0, "viridis")), "spacing components must be > 0"),
                       ((hm, (1.0, 1.0), 0.0, "viridis"), "exaggeration must be > 0"),
                       ((hm.astype(np.int32), (1.0, 1.0), 1.0, "viridis"), "heightmap must be a 2-D NumPy array of dtype float32 or float64"),
-                      ((hm[:, ::2], (1.0, 1.0), 1.0, "viridis"), "heightmap must be C-contiguous (row-major)"),
+                      # a non-contiguous float32 array fails the reference's f32 attempt AND its f64 downcast: the dtype message
+                      # (src/lib.rs:351-372); a non-contiguous float64 array reports the layout (:374-376)
+                      ((hm[:, ::2], (1.0, 1.0), 1.0, "viridis"), "heightmap must be a 2-D NumPy array of dtype float32 or float64"),
+                      ((hm.astype(np.float64)[:, ::2], (1.0, 1.0), 1.0, "viridis"), "heightmap must be C-contiguous (row-major)"),
                       ((hm, (1.0, 1.0), 1.0, "invalid_colormap"), "Unknown colormap 'invalid_colormap'. Supported: viridis, magma, terrain")):
         with pytest.raises(RuntimeError, match=re.escape(msg)):
             r.add_terrain(*args)
@@ -103,6 +106,24 @@ def test_argument_errors():
     for cm in ("viridis", "magma", "terrain"):                             # tests/test_colormap.py:105-126
         r.add_terrain(np.random.rand(64, 64).astype(np.float32), (1.0, 1.0), 1.0, cm)
         assert len(r.terrain_stats()) == 4
+
+
+def test_failed_add_terrain_keeps_the_previous_terrain():
+    """src/lib.rs:398-416: an unknown colormap is reported after the height range was stored but before self.terrain is replaced."""
+    r = vf.Renderer(16, 16)
+    first = ramp(np.float32, (6, 5))
+    r.add_terrain(first, (1.0, 1.0), 1.0, "viridis")
+    before = r.terrain_stats()
+    with pytest.raises(RuntimeError, match="Unknown colormap"):
+        r.add_terrain(np.full((9, 9), 77.0, np.float32), (1.0, 1.0), 1.0, "nope")
+    assert r.terrain_stats() == before
+    r.upload_height_r32f()
+    assert np.array_equal(r.read_full_height_texture(), first)
+    fresh = vf.Renderer(16, 16)
+    with pytest.raises(RuntimeError, match="Unknown colormap"):
+        fresh.add_terrain(first, (1.0, 1.0), 1.0, "nope")
+    with pytest.raises(RuntimeError, match="no terrain uploaded"):
+        fresh.terrain_stats()
 
 
 @pytest.mark.parametrize("shape,dtype,ex", [((64, 64), np.float32, 1.0), ((300, 1000), np.float32, 2.5), ((129, 257), np.float64, 0.5),

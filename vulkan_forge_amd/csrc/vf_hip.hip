@@ -13,6 +13,8 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types only: the functions are resolved at run time (resolve_rccl)
 
 using namespace vf;
 
@@ -85,6 +87,10 @@ struct vf_terrain {
     // uniforms
     float u[44];
     bool have_uniforms = false;
+    float u_frame[44];                   // uniforms / shade mode of the frame vf_terrain_render drew last (visibility, fragment diagnostics)
+    uint32_t shade_mode_frame = 0;
+    uint32_t *d_rgba_scratch = nullptr;  // output of those diagnostic re-renders: the caller's frame is never overwritten
+    uint32_t *d_diag = nullptr;          // [0] covered pixels (fragment-stage diagnostics)
     float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
     bool have_drawn = false, camera_moving = false, was_moving = false;
     uint32_t frames_since_reset = 0;     // frames planned since create / set_shard (the feedback arrays were cleared then)
@@ -100,7 +106,11 @@ struct vf_terrain {
     // Per-frame plan state, twice: frame f uses set f & 1.  The plan kernels of a frame run on `side` and touch nothing else,
     // so they overlap the previous frame's tile kernel (which still reads the other set) instead of waiting for it.
     struct PlanState {
-        PixelBox *ranges = nullptr;      // per block: tile rectangle
+        PixelBox *ranges = nullptr;      // per block: conservative pixel rectangle (from the block's height bounds)
+        int2 *vxy = nullptr;             // per block 81 snapped vertices (k_block_setup)
+        float *vrw = nullptr;            // per block 81 x 1/w
+        BlockRec *recs = nullptr;        // per block: alive masks, exact pixel box
+        ulonglong2 *gen = nullptr;       // per block: primitives that need the generic path (valid where the record says so)
         PixelBox *row_ranges = nullptr;  // per block row
         float4 *cap_seg = nullptr;       // per block: capsule axis (screen space)
         float *cap_rad = nullptr;        // per block: capsule radius
@@ -285,6 +295,10 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     const size_t all_tiles = (size_t)t->ntx * t->nty;
     for (auto &S : t->ps) {
         A((void **)&S.ranges, t->nblocks * sizeof(PixelBox));
+        A((void **)&S.vxy, (size_t)t->nblocks * kBlockStride * sizeof(int2));
+        A((void **)&S.vrw, (size_t)t->nblocks * kBlockStride * sizeof(float));
+        A((void **)&S.recs, (size_t)t->nblocks * sizeof(BlockRec));
+        A((void **)&S.gen, (size_t)t->nblocks * sizeof(ulonglong2));
         A((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
         A((void **)&S.cap_seg, t->nblocks * sizeof(float4));
         A((void **)&S.cap_rad, t->nblocks * sizeof(float));
@@ -303,7 +317,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
-    A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t));
+    A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t));   // + one bit per block: drawn this frame?
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
     if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
@@ -329,10 +343,10 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_rgba_scratch, t->d_diag };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
-        void *sp[] = { S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
+        void *sp[] = { S.vxy, S.vrw, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
         for (void *p : sp) if (p) (void)hipFree(p);
         if (S.planned) (void)hipEventDestroy(S.planned);
         if (S.drawn) (void)hipEventDestroy(S.drawn);
@@ -370,6 +384,7 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
     if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    VF_HIP_TRY(hipStreamSynchronize(t->side));
     size_t bytes = (size_t)tw * th * sizeof(float);
     if ((size_t)t->tw * t->th != (size_t)tw * th || t->d_height != t->d_height_own) {
         float *fresh = nullptr;                            // allocate first: a failure leaves the handle as it was
@@ -390,6 +405,10 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
     if (!t || !dev_height) return fail(VF_ERR_INVALID, "NULL argument");
     if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    // a frame still in flight (caller's stream, or the plan / height-cache kernels on the side stream) reads the axis tables
+    // and the old texture: let it finish before either changes
+    VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    VF_HIP_TRY(hipStreamSynchronize(t->side));
     t->d_height = dev_height;
     int rc = set_height_common(t, tw, th);
     if (rc != VF_OK) return rc;
@@ -605,10 +624,14 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // when those times belong to the frame still being drawn -- by a kernel of its own after the wait below
     uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
     hipLaunchKernelGGL(k_block_boxes, dim3(t->nb + 1), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi,
-                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum);
+                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count);
+    // vertex stage + tile-independent culling, once per frame (streams ~1 KB per block into this frame's plan state)
+    {
+        const uint32_t wgs = std::min<uint32_t>((t->nblocks + kSetupWaves - 1) / kSetupWaves, 8u * (uint32_t)std::max(1, t->ctx->prop.multiProcessorCount));
+        hipLaunchKernelGGL(k_block_setup, dim3(wgs), dim3(64 * kSetupWaves), 0, side, P, t->d_hblk, S.ranges, S.vxy, S.vrw, S.recs, S.gen);
+    }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
-        VF_HIP_TRY(hipMemsetAsync(S.work_count, 0, 4 * sizeof(uint32_t), side));
         if (fresh) {
             VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));         // (the block boxes above did not need to wait)
             hipLaunchKernelGGL(k_quantum, dim3(1), dim3(512), 0, side, O.feedback, t->ntx * t->nty, quantum);
@@ -622,19 +645,22 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     VF_HIP_TRY(hipEventRecord(S.planned, side));
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
-    if (t->timing) VF_HIP_TRY(hipMemsetAsync(t->d_stats, 0, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots) * sizeof(uint32_t), s));
+    const uint32_t nstats = (uint32_t)(4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32);   // zeroed by k_clear (no memset dispatch)
     VF_HIP_TRY(hipStreamWaitEvent(s, S.planned, 0));
+    // the previous frame may have been drawn on another stream of the caller's: it wrote the same output / statistics buffers
+    if (t->last_stream && t->last_stream != s && t->rendered) VF_HIP_TRY(hipStreamWaitEvent(s, O.drawn, 0));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
-        hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis);
+        hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats);
         // one persistent workgroup per CU (a 1024-thread workgroup with 70 KB of LDS fills one), the fast variant, works through
         // the items; then a handful of persistent workgroups of the complete variant take the items that met a clipped or
         // oversized primitive (normally none)
         uint32_t *redo_count = S.work_count + 3;
         const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount), ntiles + kSplitBudget)),
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
-#define VF_TILE_ARGS P, t->d_hblk, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
+        const SetupView V = { S.vxy, S.vrw, t->d_hblk, S.recs, S.gen };
+#define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, redo_count, S.redo
         if (write_vis) {
             hipLaunchKernelGGL((k_tile<true, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
@@ -658,7 +684,40 @@ int vf_terrain_render(vf_terrain *t, void *stream)
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    std::memcpy(t->u_frame, t->u, sizeof t->u_frame);
+    t->shade_mode_frame = t->shade_mode;
     return render_impl(t, stream ? (hipStream_t)stream : t->ctx->stream, false);
+}
+
+// Re-render the frame vf_terrain_render drew last with the visibility store enabled, into scratch buffers: uniforms set since,
+// the output buffer (also a caller's, vf_terrain_set_output_device), the stream later calls synchronise with, the timing ring
+// and the camera-motion state are as before afterwards.  What the extra frame does leave behind: it uses one of the two plan
+// states and adds its tile times to that state's scheduling feedback -- the same view as the frame before it, so the feedback
+// stays valid -- and the next frame plans with the other state.
+static int render_visibility(vf_terrain *t)
+{
+    const size_t npx = (size_t)t->ntx * t->nty * kTileW * kTileH;
+    if (!t->d_vis) VF_HIP_TRY(hipMalloc(&t->d_vis, npx * sizeof(uint32_t)));
+    if (!t->d_rgba_scratch) VF_HIP_TRY(hipMalloc(&t->d_rgba_scratch, npx * sizeof(uint32_t)));
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    float u_now[44], u_drawn[32];
+    std::memcpy(u_now, t->u, sizeof u_now); std::memcpy(u_drawn, t->u_drawn, sizeof u_drawn);
+    uint32_t *const out_now = t->d_rgba;
+    const hipStream_t stream_now = t->last_stream;
+    const bool timing = t->timing, have_drawn = t->have_drawn, moving = t->camera_moving, was_moving = t->was_moving;
+    const uint32_t mode_now = t->shade_mode, since = t->frames_since_reset;
+    if (t->rendered) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; }
+    t->d_rgba = t->d_rgba_scratch; t->timing = false;
+    rc = render_impl(t, t->ctx->stream, true);
+    hipError_t e = hipStreamSynchronize(t->ctx->stream);
+    std::memcpy(t->u, u_now, sizeof u_now); std::memcpy(t->u_drawn, u_drawn, sizeof u_drawn);
+    t->d_rgba = out_now; t->last_stream = stream_now; t->timing = timing; t->have_drawn = have_drawn;
+    t->camera_moving = moving; t->was_moving = was_moving; t->shade_mode = mode_now; t->frames_since_reset = since;
+    if (rc != VF_OK) return rc;
+    if (e != hipSuccess) return fail(VF_ERR_HIP, std::string("visibility render: ") + hipGetErrorString(e));
+    return VF_OK;
 }
 
 int vf_terrain_sync(vf_terrain *t)
@@ -766,15 +825,69 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst)
     if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
     if (t->shard_tiles) return fail(VF_ERR_INVALID, "visibility read-back needs a row-oriented handle (vf_terrain_set_shard)");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
-    // the visibility tile normally lives and dies in LDS: re-render the current frame with the debug store enabled
-    const size_t npx = (size_t)t->W * t->H;
-    if (!t->d_vis) VF_HIP_TRY(hipMalloc(&t->d_vis, npx * sizeof(uint32_t)));
-    int rc = vf_terrain_sync(t);
+    // the visibility tile normally lives and dies in LDS: the last frame is rendered again with the debug store enabled
+    int rc = render_visibility(t);
     if (rc != VF_OK) return rc;
-    rc = render_impl(t, t->ctx->stream, true);
-    if (rc != VF_OK) return rc;
-    VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));
     VF_HIP_TRY(hipMemcpy(dst, t->d_vis, (size_t)t->local_rows * t->W * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VF_OK;
+}
+
+int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment_timing *out)
+{
+    if (!t || !out) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
+    if (t->shard_tiles || t->nranks != 1) return fail(VF_ERR_INVALID, "fragment-stage diagnostics need a whole-frame handle");
+    if (repeats == 0) repeats = 1;
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    int rc = render_visibility(t);                          // d_vis + the frame as the tile kernel shades it (d_rgba_scratch)
+    if (rc != VF_OK) return rc;
+    const size_t npx = (size_t)t->W * t->H;
+    uint32_t *d_out = nullptr;
+    VF_HIP_TRY(hipMalloc(&d_out, npx * sizeof(uint32_t)));
+    if (!t->d_diag) { hipError_t e = hipMalloc(&t->d_diag, 4 * sizeof(uint32_t)); if (e != hipSuccess) { (void)hipFree(d_out); return fail(VF_ERR_NOMEM, "diagnostics allocation failed"); } }
+    uint32_t redo = 0;                                      // did the frame hold clipped / oversized primitives?  (normally not)
+    hipError_t err = hipMemcpy(&redo, t->ps[(t->frame_no - 1u) & 1u].work_count + 3, sizeof redo, hipMemcpyDeviceToHost);
+    FrameParams P;
+    float u_now[44];
+    std::memcpy(u_now, t->u, sizeof u_now);
+    const uint32_t mode_now = t->shade_mode;
+    if (t->rendered) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; }
+    build_params(t, P);
+    std::memcpy(t->u, u_now, sizeof u_now); t->shade_mode = mode_now;
+    hipStream_t s = t->ctx->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    const dim3 grid(((t->W + 255u) / 256u) * t->H), threads(256);
+    const vf_terrain::PlanState &S = t->ps[(t->frame_no - 1u) & 1u];     // the set-up of the frame just rendered
+    const SetupView V = { S.vxy, S.vrw, t->d_hblk, S.recs, S.gen };
+    auto launch = [&](uint32_t *covered) {
+        if (redo) hipLaunchKernelGGL((k_resolve<true>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+        else hipLaunchKernelGGL((k_resolve<false>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+    };
+    if (err == hipSuccess) err = hipMemsetAsync(t->d_diag, 0, 4 * sizeof(uint32_t), s);
+    if (err == hipSuccess) { launch(t->d_diag); err = hipGetLastError(); }       // warm-up launch, counts the covered pixels
+    if (err == hipSuccess) err = hipEventRecord(e0, s);
+    for (uint32_t k = 0; k < repeats && err == hipSuccess; ++k) { launch(nullptr); err = hipGetLastError(); }
+    if (err == hipSuccess) err = hipEventRecord(e1, s);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    uint32_t covered = 0;
+    if (err == hipSuccess) err = hipMemcpy(&covered, t->d_diag, sizeof covered, hipMemcpyDeviceToHost);
+    // the resolved frame against the one the tile kernel produced (row-major whole frame in both buffers)
+    uint32_t equal = 0;
+    if (err == hipSuccess) {
+        std::vector<uint32_t> a(npx), b(npx);
+        err = hipMemcpy(a.data(), d_out, npx * 4, hipMemcpyDeviceToHost);
+        if (err == hipSuccess) err = hipMemcpy(b.data(), t->d_rgba_scratch, npx * 4, hipMemcpyDeviceToHost);
+        if (err == hipSuccess) equal = std::memcmp(a.data(), b.data(), npx * 4) == 0 ? 1u : 0u;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    if (err != hipSuccess) return fail(VF_ERR_HIP, std::string("fragment-stage diagnostics: ") + hipGetErrorString(err));
+    out->resolve_ms = ms / (float)repeats; out->covered_pixels = covered; out->repeats = repeats; out->equal_to_frame = equal;
     return VF_OK;
 }
 
@@ -847,6 +960,13 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
     VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));
     out->blocks_rasterised = c[0];
     out->tiles = t->local_tiles;
+    {   // distinct blocks behind those pairs (last frame): the bitmap behind the per-item statistics
+        std::vector<uint32_t> bits((t->nblocks + 31) / 32);
+        VF_HIP_TRY(hipMemcpy(bits.data(), t->d_stats + 4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t n = 0;
+        for (uint32_t w : bits) n += (uint32_t)__builtin_popcount(w);
+        out->blocks_distinct = n;
+    }
     return VF_OK;
 }
 
@@ -1157,6 +1277,190 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     hipLaunchKernelGGL(k_stitch_tiles, dim3(ntx * nty), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
                        ntx, nranks, skew, stride_tiles);
     VF_HIP_TRY(hipGetLastError());
+    return VF_OK;
+}
+
+} // extern "C"
+
+// ---- multi-GPU exchange over RCCL ---------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    bool ok = false;
+    std::string why;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+// librccl.so.1 as already loaded in the process (PyTorch brings its own copy; a second one would not share its state), else
+// the ROCm installation's through this library's run path
+const Rccl &resolve_rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) { x.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return x; }
+        bool all = true;
+        auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) { all = false; x.why = std::string("RCCL lacks ") + name; } return p; };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+        x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(sym("ncclCommUserRank"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+        x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
+        x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.ok = all;
+        return x;
+    }();
+    return r;
+}
+#define VF_RCCL_TRY(R, expr)                                                                                   \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(VF_ERR_HIP, std::string(#expr) + ": " + (R).GetErrorString(r_));   \
+    } while (0)
+
+// rank and size of the communicator must be the handle's shard: a mismatch would exchange the wrong slabs silently
+int check_comm(const Rccl &R, const vf_terrain *t, void *comm, int root)
+{
+    if (!R.ok) return fail(VF_ERR_HIP, R.why);
+    if (!comm) return fail(VF_ERR_INVALID, "communicator is NULL");
+    int n = 0, r = -1;
+    VF_RCCL_TRY(R, R.CommCount((ncclComm_t)comm, &n));
+    VF_RCCL_TRY(R, R.CommUserRank((ncclComm_t)comm, &r));
+    if ((uint32_t)n != t->nranks || (uint32_t)r != t->rank) return fail(VF_ERR_INVALID, "communicator rank/size differ from the handle's shard");
+    if (root < 0 || root >= n) return fail(VF_ERR_INVALID, "root must be a rank of the communicator");
+    return VF_OK;
+}
+} // namespace
+
+extern "C" {
+
+int vf_dist_available(void) { return resolve_rccl().ok ? 1 : 0; }
+
+int vf_dist_unique_id(uint8_t id[VF_DIST_UNIQUE_ID_BYTES])
+{
+    if (!id) return fail(VF_ERR_INVALID, "NULL argument");
+    const Rccl &R = resolve_rccl();
+    if (!R.ok) return fail(VF_ERR_HIP, R.why);
+    static_assert(sizeof(ncclUniqueId) == VF_DIST_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    VF_RCCL_TRY(R, R.GetUniqueId(&u));
+    std::memcpy(id, u.internal, sizeof u.internal);
+    return VF_OK;
+}
+
+int vf_dist_comm_init(vf_ctx *ctx, const uint8_t id[VF_DIST_UNIQUE_ID_BYTES], int rank, int nranks, void **comm)
+{
+    if (!ctx || !id || !comm) return fail(VF_ERR_INVALID, "NULL argument");
+    *comm = nullptr;
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
+    const Rccl &R = resolve_rccl();
+    if (!R.ok) return fail(VF_ERR_HIP, R.why);
+    VF_HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, sizeof u.internal);
+    ncclComm_t c = nullptr;
+    VF_RCCL_TRY(R, R.CommInitRank(&c, nranks, u, rank));
+    *comm = c;
+    return VF_OK;
+}
+
+void vf_dist_comm_destroy(void *comm)
+{
+    const Rccl &R = resolve_rccl();
+    if (R.ok && comm) (void)R.CommDestroy((ncclComm_t)comm);
+}
+
+int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gathered, uint32_t stride_tiles, void *stream)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->shard_tiles) return fail(VF_ERR_INVALID, "handle is not tile-sharded");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    const Rccl &R = resolve_rccl();
+    int rc = check_comm(R, t, rccl_comm, root);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    ncclComm_t comm = (ncclComm_t)rccl_comm;
+    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
+    if (s != t->last_stream && t->last_stream) {            // the slab is being drawn on another stream: order the exchange after it
+        VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+    }
+    const size_t tile_bytes = (size_t)kTileW * kTileH * 4;
+    const bool is_root = (uint32_t)root == t->rank;
+    if (is_root) {
+        if (!dev_gathered) return fail(VF_ERR_INVALID, "the root needs the gather buffer");
+        for (uint32_t r = 0; r < t->nranks; ++r) {
+            uint32_t n = 0;
+            rc = vf_tile_layout(t->W, t->H, r, t->nranks, t->skew, nullptr, 0, &n);
+            if (rc != VF_OK) return rc;
+            if (n > stride_tiles) return fail(VF_ERR_INVALID, "stride_tiles is smaller than the largest shard");
+        }
+    }
+    uint8_t *const slots = (uint8_t *)dev_gathered;
+    uint8_t *const own_slot = is_root ? slots + (size_t)root * stride_tiles * tile_bytes : nullptr;
+    const bool in_place = is_root && (uint8_t *)t->d_rgba == own_slot;
+    VF_RCCL_TRY(R, R.GroupStart());
+    ncclResult_t res = ncclSuccess;
+    if (is_root) {
+        for (uint32_t r = 0; r < t->nranks && res == ncclSuccess; ++r) {
+            if (r == t->rank && in_place) continue;         // the root drew straight into its slot
+            uint32_t n = 0;
+            (void)vf_tile_layout(t->W, t->H, r, t->nranks, t->skew, nullptr, 0, &n);
+            if (n) res = R.Recv(slots + (size_t)r * stride_tiles * tile_bytes, (size_t)n * tile_bytes, ncclUint8, (int)r, comm, s);
+        }
+    }
+    if (res == ncclSuccess && (!is_root || !in_place) && t->local_tiles)
+        res = R.Send(t->d_rgba, (size_t)t->local_tiles * tile_bytes, ncclUint8, root, comm, s);
+    const ncclResult_t end = R.GroupEnd();
+    if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
+    if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
+    return VF_OK;
+}
+
+int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (t->shard_tiles) return fail(VF_ERR_INVALID, "handle is tile-sharded: gather with vf_dist_gather_tiles");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    const Rccl &R = resolve_rccl();
+    int rc = check_comm(R, t, rccl_comm, root);
+    if (rc != VF_OK) return rc;
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    ncclComm_t comm = (ncclComm_t)rccl_comm;
+    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
+    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+    const bool is_root = (uint32_t)root == t->rank;
+    if (is_root && !dev_image) return fail(VF_ERR_INVALID, "the root needs the image buffer");
+    const size_t row_bytes = (size_t)t->W * 4;
+    std::vector<uint32_t> local(t->nranks, 0u);             // rows a rank has stored so far, band by band
+    VF_RCCL_TRY(R, R.GroupStart());
+    ncclResult_t res = ncclSuccess;
+    hipError_t herr = hipSuccess;
+    for (uint32_t b = 0; b * t->band_h < t->H && res == ncclSuccess && herr == hipSuccess; ++b) {
+        const uint32_t y0 = b * t->band_h, rows = std::min(t->band_h, t->H - y0), owner = b % t->nranks, ly0 = local[owner];
+        local[owner] += rows;
+        uint8_t *dst = is_root ? (uint8_t *)dev_image + (size_t)y0 * row_bytes : nullptr;
+        const uint8_t *src = (const uint8_t *)t->d_rgba + (size_t)ly0 * row_bytes;
+        if (owner == t->rank && is_root) { if ((const uint8_t *)dst != src) herr = hipMemcpyAsync(dst, src, rows * row_bytes, hipMemcpyDeviceToDevice, s); }
+        else if (is_root) res = R.Recv(dst, rows * row_bytes, ncclUint8, (int)owner, comm, s);
+        else if (owner == t->rank) res = R.Send(src, rows * row_bytes, ncclUint8, root, comm, s);
+    }
+    const ncclResult_t end = R.GroupEnd();
+    if (herr != hipSuccess) return fail(VF_ERR_HIP, std::string("band copy: ") + hipGetErrorString(herr));
+    if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
+    if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
     return VF_OK;
 }
 

@@ -109,9 +109,13 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
                                                      PixelBox *__restrict__ boxes, PixelBox *__restrict__ row_boxes,
                                                      float4 *__restrict__ cap_seg, float *__restrict__ cap_rad,
                                                      uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi,
-                                                     const uint32_t *__restrict__ feedback, uint32_t ntiles_all, uint32_t *__restrict__ quantum)
+                                                     const uint32_t *__restrict__ feedback, uint32_t ntiles_all, uint32_t *__restrict__ quantum,
+                                                     uint32_t *__restrict__ work_count)
 {
     if (blockIdx.x == P.nb) {                               // (uniform per workgroup)
+        // this frame's queue words start at zero: [0] work items, [1] split budget used, [2] queue head, [3] items for the complete
+        // kernel (k_plan, next on this stream, is their first user; a memset here would be one more dispatch in a latency-bound chain)
+        if (threadIdx.x < 4u) work_count[threadIdx.x] = 0u;
         if (feedback) publish_quantum(feedback, ntiles_all, quantum);
         return;
     }
@@ -205,6 +209,105 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
         else { rr.x0 = (int16_t)s_rr[0]; rr.y0 = (int16_t)s_rr[1]; rr.x1 = (int16_t)s_rr[2]; rr.y1 = (int16_t)s_rr[3]; }
         row_boxes[by] = rr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per frame: vs_main (src/shaders/terrain.wgsl:44-66) for every vertex of every block that can reach the target, once, and the
+// tile-independent part of primitive assembly / culling (src/terrain/pipeline.rs:124-132: front = CCW, cull back; clip to
+// 0 <= z <= w).  One wave per block at a time:
+//   1. 9 x 9 displaced heights (two coalesced loads from the cache) -> clip coordinates -> 24.8 snapped X, Y, 1/w and clip flags;
+//      X, Y (648 B) and 1/w (324 B) go to HBM for the tile kernel's raster and fragment stages;
+//   2. lane = cell: both primitives are classified -- dead (non-finite, outside near/far, not projectable, bounding box without a
+//      pixel centre of the target, back-facing or degenerate), generic (needs clipping / oversized) or alive;
+//   3. alive masks by ballot, exact union of the alive primitives' pixel boxes by wave reduction -> BlockRec.
+// Streaming: 324 B read, ~1 KB written per block.  The tile kernel then loads instead of recomputing -- each block is looked at
+// by 1.9 tiles on average, by 16 strips of a heavy tile on a multi-GPU rank -- and never touches a block without alive primitives.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSetupWaves = 4;
+__global__ __launch_bounds__(64 * kSetupWaves) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
+                                                                  const PixelBox *__restrict__ cons_boxes, int2 *__restrict__ vxy,
+                                                                  float *__restrict__ vrw, BlockRec *__restrict__ recs,
+                                                                  ulonglong2 *__restrict__ gen)
+{
+    constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
+    __shared__ int32_t sX[kSetupWaves][kNV];
+    __shared__ int32_t sY[kSetupWaves][kNV];
+    __shared__ uint8_t sF[kSetupWaves][kNV + 3];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nblocks = P.nb * P.nb;
+    for (uint32_t b = blockIdx.x * kSetupWaves + wave; b < nblocks; b += gridDim.x * kSetupWaves) {
+        const PixelBox cb = cons_boxes[b];                 // conservative box of the block's height bounds (k_block_boxes)
+        BlockRec rec;
+        rec.box = PixelBox{ 1, 1, 0, 0 }; rec.flags = 0u; rec.count = 0u; rec.alive_even = 0ull; rec.alive_odd = 0ull;
+        if (cb.x0 > cb.x1) {                               // (uniform) clipped away or off the target: nothing to set up
+            if (lane == 0) recs[b] = rec;
+            continue;
+        }
+        const uint32_t bx = b % P.nb, by = b / P.nb;
+        const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
+        const float *hb = hblk + (size_t)b * kBlockStride;
+        for (int v = lane; v < kNV; v += 64) {
+            const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
+            const uint32_t i = i0 + li, j = j0 + lj;
+            int32_t X = 0, Y = 0;
+            float rw = 0.0f;
+            uint32_t fl = F_BAD;
+            if (i < P.n && j < P.n) {
+                ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), hb[v]);
+                fl = vertex_flags(cv);
+                if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
+            }
+            sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
+            vxy[(size_t)b * kBlockStride + v] = make_int2(X, Y);
+            vrw[(size_t)b * kBlockStride + v] = rw;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane = cell
+        const uint32_t lj = lane >> 3, li = lane & 7u;
+        int c0 = 0, c1 = 0;                                // 0 dead, 1 alive, 2 generic
+        int32_t bx0 = 0x7FFF, by0 = 0x7FFF, bx1 = -1, by1 = -1;
+        if (i0 + li < P.nm1 && j0 + lj < P.nm1) {
+            const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
+            const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
+            const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
+            const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
+            auto classify = [&](uint32_t f0, uint32_t f1, uint32_t f2, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2) -> int {
+                const uint32_t any = f0 | f1 | f2, all = f0 & f1 & f2;
+                if (any & F_BAD) return 0;                            // non-finite clip coordinate: primitive dropped
+                if (all & (F_NEAR | F_FAR)) return 0;                 // entirely outside the near or the far plane
+                if (any & (F_NEAR | F_FAR)) return 2;                 // needs clipping
+                if (any & F_NOSNAP) return 0;                         // a vertex could not be projected (w <= 0)
+                const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+                const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+                if ((uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kFastExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kFastExtent) return 2;
+                const int32_t px0 = max((xmin + 127) >> 8, 0), px1 = min((xmax - 128) >> 8, (int32_t)P.W - 1);
+                const int32_t py0 = max((ymin + 127) >> 8, 0), py1 = min((ymax - 128) >> 8, (int32_t)P.H - 1);
+                if (px0 > px1 || py0 > py1) return 0;                 // no pixel centre of the target inside the bounding box
+                const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
+                if (area2 >= 0) return 0;                             // back-facing or degenerate
+                bx0 = min(bx0, px0); by0 = min(by0, py0); bx1 = max(bx1, px1); by1 = max(by1, py1);
+                return 1;
+            };
+            c0 = classify(fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);        // (a, c, b)
+            c1 = classify(fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);        // (b, c, d)
+        }
+        const unsigned long long a0 = __ballot(c0 == 1), a1 = __ballot(c1 == 1), g0 = __ballot(c0 == 2), g1 = __ballot(c1 == 2);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
+            bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
+        }
+        rec.alive_even = a0; rec.alive_odd = a1;
+        rec.count = (uint32_t)(__popcll(a0) + __popcll(a1));
+        if (g0 | g1) { rec.flags = kRecGeneric; rec.box = cb; }      // generic primitives: only the conservative bound holds
+        else if (rec.count) rec.box = PixelBox{ (int16_t)bx0, (int16_t)by0, (int16_t)bx1, (int16_t)by1 };
+        if (lane == 0) {
+            recs[b] = rec;
+            if (g0 | g1) gen[b] = make_ulonglong2(g0, g1);
+        }
+        __builtin_amdgcn_wave_barrier();                    // the next block reuses this wave's LDS slot
     }
 }
 
@@ -389,24 +492,15 @@ __device__ __noinline__ void raster_generic(const GVert v[3], float hw, float hh
     }
 }
 
-// classification of one primitive against the tile: 0 = nothing to draw, 1 = fast path, 2 = generic path
-__device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uint32_t fl1, uint32_t fl2, int32_t X0, int32_t Y0,
-                                             int32_t X1, int32_t Y1, int32_t X2, int32_t Y2 VF_RC_ARG)
+// Tile-dependent part of the classification of a primitive k_block_setup found alive (no clipping needed, front-facing, a pixel
+// centre of the target inside its bounding box): does it hold a pixel centre of this tile that is still open?
+__device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2 VF_RC_ARG)
 {
-    const uint32_t any = fl0 | fl1 | fl2, all = fl0 & fl1 & fl2;
-    if (any & F_BAD) return 0;                            // non-finite clip coordinate: primitive dropped
-    if (all & (F_NEAR | F_FAR)) return 0;                 // entirely outside the near or the far plane
-    if (any & (F_NEAR | F_FAR)) return 2;                 // needs clipping
-    if (any & F_NOSNAP) return 0;                         // a vertex could not be projected (w <= 0)
     const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
     const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-    if ((uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kFastExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kFastExtent) return 2;
     const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
     const int32_t py0 = max((ymin + 127) >> 8, T.py_lo), py1 = min((ymax - 128) >> 8, T.py_hi);
-    if (px0 > px1 || py0 > py1) return 0;                 // no pixel centre of the tile inside the bbox
-    // facing: extents < 2^24, so the products fit comfortably in 64 bits
-    const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
-    if (area2 >= 0) return 0;                             // back-facing or degenerate
+    if (px0 > px1 || py0 > py1) return false;             // no pixel centre of the tile inside the bbox
     // occlusion: every candidate pixel already final
     const bool cols = (px1 - px0) <= (py1 - py0);
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
@@ -422,9 +516,9 @@ __device__ __forceinline__ int classify_prim(const TileCtx &T, uint32_t fl0, uin
         uint64_t all = load_mask(fin, o);
 #pragma unroll
         for (int d = 1; d < VF_CLS_LINES; ++d) all &= load_mask(fin, min(o + d, o1));
-        if (~all & seg) return 1;
+        if (~all & seg) return true;
     }
-    return 0;
+    return false;
 }
 
 // ---- fragment stage ---------------------------------------------------------------------------
@@ -496,25 +590,65 @@ __device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, floa
 
 __device__ __forceinline__ bool vertex_plain(const GVert &v) { return finite4(v.x, v.y, v.z, v.w) && !(v.z < 0.0f) && !(v.z > v.w); }
 
+// What the fragment stage needs of the frame's set-up (k_block_setup): snapped vertices, 1/w, displaced heights, block records.
+struct SetupView {
+    const int2 *vxy;            // per block 81 x (X, Y), 24.8 fixed point
+    const float *vrw;           // per block 81 x 1/w
+    const float *hblk;          // per block 81 displaced heights (the `height` varying)
+    const BlockRec *recs;
+    const ulonglong2 *gen;      // per block: which primitives need the generic path (valid where kRecGeneric is set)
+};
+
+// Varyings + fs_main for the primitive that owns pixel (px, py).  The three vertices come from the set-up arrays -- the vertex
+// stage ran once per frame -- so this is loads, three exact edge functions (FP64: operands are integers < 2^25, every product and
+// sum stays below 2^53) and the perspective-correct interpolation of (height, x, z).
 // CLIPPED = false: the caller never put a near/far-clipped primitive into the visibility tile (the fast tile kernel), so the
-// clipping code -- calls, stack arrays, scratch memory -- is not compiled in at all.
+// clipping code -- calls, stack arrays, scratch memory, the vertex shader -- is not compiled in at all.
 template <bool CLIPPED>
-__device__ inline uint32_t shade_pixel(const FrameParams &P, const float *__restrict__ hblk,
-                                       const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
+__device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V, const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
-    GVert v0, v1, v2;
-    load_prim(P, hblk, prim, v0, v1, v2);
-    float attr[3] = { 0.f, 0.f, 0.f };
-    bool hit = false;
-    if (vertex_plain(v0) && vertex_plain(v1) && vertex_plain(v2)) {
-        TriSetup T;
-        int64_t e[3];
-        if (setup_triangle(v0, v1, v2, P.hw, P.hh, P.W, P.H, T) && covers(T, px, py, e)) { interpolate(T, e, attr); hit = true; }
-    } else if constexpr (CLIPPED) {
-        const GVert v[3] = { v0, v1, v2 };                 // only the clipped path keeps the vertices in memory
-        hit = clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr);
+    // indices [a,c,b, b,c,d] (src/terrain/mod.rs:578-582): even = (a, c, b), odd = (b, c, d)
+    const uint32_t cell = prim >> 1, odd = prim & 1u;
+    const uint32_t j = cell / P.nm1, i = cell - j * P.nm1;
+    const uint32_t li = i & 7u, lj = j & 7u;
+    const size_t b = (size_t)(j >> 3) * P.nb + (i >> 3);
+    if constexpr (CLIPPED) {
+        if (V.recs[b].flags & kRecGeneric) {
+            const ulonglong2 g = V.gen[b];
+            if (((odd ? g.y : g.x) >> (lj * 8u + li)) & 1ull) {
+                GVert v[3];                                // only the clipped path keeps the vertices in memory
+                load_prim(P, V.hblk, prim, v[0], v[1], v[2]);
+                float attr[3] = { 0.f, 0.f, 0.f };
+                if (!clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr)) return P.clear_rgba;   // unreachable when the visibility tile is consistent
+                return fragment_shader(P, S, attr);
+            }
+        }
     }
-    if (!hit) return P.clear_rgba;   // unreachable when the visibility tile is consistent
+    const uint32_t va = lj * kBlockVerts + li;
+    const uint32_t l0 = odd ? va + 1u : va, l1 = va + kBlockVerts, l2 = odd ? va + kBlockVerts + 1u : va + 1u;
+    const size_t base = b * kBlockStride;
+    const int2 p0 = V.vxy[base + l0], p1 = V.vxy[base + l1], p2 = V.vxy[base + l2];
+    const float rw0 = V.vrw[base + l0], rw1 = V.vrw[base + l1], rw2 = V.vrw[base + l2];
+    const float h0 = V.hblk[base + l0], h1 = V.hblk[base + l1], h2 = V.hblk[base + l2];
+    // varyings xz (terrain.wgsl:64): vertex 0 = (i + odd, j), vertex 1 = (i, j + 1), vertex 2 = (i + 1, j + odd)
+    const float x0 = grid_coord(P, i + odd), x1 = grid_coord(P, i), x2 = grid_coord(P, i + 1u);
+    const float z0 = grid_coord(P, j), z1 = grid_coord(P, j + 1u), z2 = grid_coord(P, j + odd);
+    // inside-positive edge weights at the pixel centre (covers() / edge_fn() in int64, here exactly the same values in FP64)
+    const double Px = (double)(px * 256 + 128), Py = (double)(py * 256 + 128);
+    const double X0 = p0.x, Y0 = p0.y, X1 = p1.x, Y1 = p1.y, X2 = p2.x, Y2 = p2.y;
+    const double e0 = -fma(X2 - X1, Py - Y1, -((Y2 - Y1) * (Px - X1)));
+    const double e1 = -fma(X0 - X2, Py - Y2, -((Y0 - Y2) * (Px - X2)));
+    const double e2 = -fma(X1 - X0, Py - Y0, -((Y1 - Y0) * (Px - X0)));
+    const double area2 = fma(X1 - X0, Y2 - Y0, -((Y1 - Y0) * (X2 - X0)));
+    // interpolate(): lambda_i = e_i / -area2 in float, perspective q_i = lambda_i / w_i
+    const float fA = (float)(-area2);
+    const float la0 = (float)e0 / fA, la1 = (float)e1 / fA, la2 = (float)e2 / fA;
+    const float q0 = la0 * rw0, q1 = la1 * rw1, q2 = la2 * rw2;
+    const float rQ = 1.0f / ((q0 + q1) + q2);
+    float attr[3];
+    attr[0] = fmaf(q2, h2, fmaf(q1, h1, q0 * h0)) * rQ;
+    attr[1] = fmaf(q2, x2, fmaf(q1, x1, q0 * x0)) * rQ;
+    attr[2] = fmaf(q2, z2, fmaf(q1, z1, q0 * z0)) * rQ;
     return fragment_shader(P, S, attr);
 }
 
@@ -735,8 +869,10 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
 // Background tiles: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
 // (this pass is pure HBM write bandwidth: 49 MiB of the C4 default frame); edge tiles and odd widths go pixel by pixel.
 __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__restrict__ background, uint32_t *__restrict__ rgba,
-                                               uint32_t *__restrict__ vis_out)
+                                               uint32_t *__restrict__ vis_out, uint32_t *__restrict__ stats, uint32_t nstats)
 {
+    // diagnostics (timing enabled): this frame's per-item statistics start at zero -- spread over the launch, no memset dispatch
+    if (stats) for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < nstats; k += gridDim.x * 256u) stats[k] = 0u;
     if ((background[blockIdx.x] & 1u) == 0u) return;
     int32_t px_lo, px_hi, py_lo, py_hi;
     const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
@@ -815,8 +951,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
 // of the main kernel leaves it without scratch memory and without a single spilled vector register.
 template <bool WRITE_VIS, bool COMPLETE>
-__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const float *__restrict__ hblk,
-                                                       const PixelBox *__restrict__ boxes, const PixelBox *__restrict__ row_boxes,
+__global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameParams P, SetupView V, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
                                                        const uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
@@ -832,10 +967,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams P, const floa
     constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
     constexpr int kRescanEvery = VF_RESCAN_EVERY;          // publish new masks when the frontier moved this many steps
     __shared__ uint32_t s_vis[kTileW * kTileH];
-    __shared__ int32_t sX[kWaves][kNV];
-    __shared__ int32_t sY[kWaves][kNV];
-    __shared__ uint8_t sF[kWaves][kNV + 3];
-    __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: surviving triangles of the current block
+    __shared__ int2 sXY[kWaves][kNV];                      // per wave: snapped vertices of the current block (from k_block_setup)
+    __shared__ uint8_t sC[kWaves][2 * kBlockCells * kBlockCells];   // per wave: the block's alive primitives (cell << 1 | odd), compacted
+    __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: those of them that survive against this tile
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
     __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
     __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
@@ -967,7 +1101,7 @@ next_item:
                     box[r] = PixelBox{ 1, 1, 0, 0 }; seg[r] = make_float4(0.f, 0.f, 0.f, 0.f); rad[r] = 0.0f;
                     if (in[r]) {
                         const uint32_t bidx = by[r] * P.nb + bx;
-                        box[r] = boxes[bidx]; seg[r] = cap_seg[bidx]; rad[r] = cap_rad[bidx];
+                        box[r] = V.recs[bidx].box; seg[r] = cap_seg[bidx]; rad[r] = cap_rad[bidx];
                     }
                 }
 #pragma unroll
@@ -1035,9 +1169,10 @@ next_item:
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
             // late culling against the masks published since the list was built (one column / row per lane)
+            const BlockRec *rec = V.recs + (by * P.nb + bx);         // (wave-uniform address)
             bool live;
             {
-                const PixelBox b = boxes[by * P.nb + bx];
+                const PixelBox b = rec->box;
                 const int32_t x0 = max((int32_t)b.x0, T.px_lo) - T.px_lo, x1 = min((int32_t)b.x1, T.px_hi) - T.px_lo;
                 const int32_t y0 = max((int32_t)b.y0, T.py_lo) - T.py_lo, y1 = min((int32_t)b.y1, T.py_hi) - T.py_lo;
                 const bool in = (int32_t)lane >= x0 && (int32_t)lane <= x1;
@@ -1047,51 +1182,59 @@ next_item:
             VF_PH(1)
             if (live) {
                 ++my_blocks;
+                if (stats && lane == 0) {                  // diagnostics: which blocks were drawn by at least one tile this frame
+                    const uint32_t bi = by * P.nb + bx;
+                    atomicOr(&stats[4u + 4u * (P.ntx * P.nty + kSplitBudget) + 2u * kPhaseSlots + (bi >> 5)], 1u << (bi & 31u));
+                }
                 const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
-                const float *hb = hblk + (size_t)(by * P.nb + bx) * kBlockStride;
-                // ---- vertex stage: 9 x 9 vertices -> snapped screen coordinates in this wave's LDS slot ----
-                for (int v = lane; v < kNV; v += 64) {
-                    const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
-                    const uint32_t i = i0 + li, j = j0 + lj;
-                    int32_t X = 0, Y = 0;
-                    uint32_t fl = F_BAD;
-                    if (i < P.n && j < P.n) {
-                        float rw;
-                        ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), hb[v]);
-                        fl = vertex_flags(cv);
-                        if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
-                    }
-                    sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
+                // ---- set-up stage, once per frame in k_block_setup: here the block's snapped vertices and alive masks are loads ----
+                const unsigned long long alive_e = rec->alive_even, alive_o = rec->alive_odd;
+                const uint32_t rflags = rec->flags;
+                {
+                    const int2 *src = V.vxy + (size_t)(by * P.nb + bx) * kBlockStride;
+                    const int2 xa = src[lane];
+                    int2 xb = make_int2(0, 0);
+                    if (lane < (uint32_t)(kNV - 64)) xb = src[64u + lane];
+                    sXY[wave][lane] = xa;
+                    if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
+                }
+                if (!COMPLETE && (rflags & kRecGeneric)) { if (lane == 0) s_redo = 1u; }   // rare: clipped / oversized -> the COMPLETE launch
+                // the alive primitives as a dense list: cell c's even primitive sits at popcount(alive_e below c), its odd one behind all
+                // the even ones -- every lane of the classification below then holds a primitive that can draw
+                const uint32_t n_even = (uint32_t)__popcll(alive_e), n_alive = n_even + (uint32_t)__popcll(alive_o);
+                {
+                    const uint32_t pe = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive_e >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive_e, 0u));
+                    const uint32_t po = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive_o >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive_o, 0u));
+                    if ((alive_e >> lane) & 1ull) sC[wave][pe] = (uint8_t)(2u * lane);
+                    if ((alive_o >> lane) & 1ull) sC[wave][n_even + po] = (uint8_t)(2u * lane + 1u);
                 }
                 __builtin_amdgcn_wave_barrier();   // LDS ops of one wave complete in order; keep the compiler from reordering
                 VF_PH(2)
-                // ---- pass A: lane = cell: classify both triangles, compact the survivors (ballot + prefix popcount) ----
-                uint32_t nsurv = 0;
-                {
+                if constexpr (COMPLETE) if (rflags & kRecGeneric) {
+                    // lane = cell: the primitives k_block_setup marked generic go through clipping and the per-pixel int64 test
+                    const ulonglong2 g = V.gen[by * P.nb + bx];
                     const uint32_t lj = lane >> 3, li = lane & 7u;
-                    const uint32_t i = i0 + li, j = j0 + lj;
-                    int k0 = 0, k1 = 0;
-                    if (i < P.nm1 && j < P.nm1) {
-                        const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-                        const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
-                        const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
-                        const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
-                        k0 = classify_prim(T, fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb VF_RC(, RC));          // (a, c, b)
-                        k1 = classify_prim(T, fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd VF_RC(, RC));          // (b, c, d)
-                        if (!COMPLETE && (k0 == 2 || k1 == 2)) s_redo = 1u;                  // rare: clipped / oversized -> the COMPLETE launch
-                        if constexpr (COMPLETE) if (k0 == 2 || k1 == 2) {
-                            const uint32_t prim = 2u * (j * P.nm1 + i);
-                            GVert gv[3];                                               // in memory only on this rare path
-                            if (k0 == 2) { load_prim(P, hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
-                            if (k1 == 2) { load_prim(P, hblk, prim + 1u, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
-                        }
+                    const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li));
+                    GVert gv[3];                                               // in memory only on this rare path
+                    if ((g.x >> lane) & 1ull) { load_prim(P, V.hblk, prim, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 1u); }
+                    if ((g.y >> lane) & 1ull) { load_prim(P, V.hblk, prim + 1u, gv[0], gv[1], gv[2]); raster_generic(gv, P.hw, P.hh, P.W, P.H, T.vis, T.px_lo, T.px_hi, T.py_lo, T.py_hi, prim + 2u); }
+                }
+                // ---- pass A: lane = alive primitive: bbox against the tile, occlusion; compact the survivors (ballot + prefix popcount) ----
+                uint32_t nsurv = 0;
+                for (uint32_t k0 = 0; k0 < n_alive; k0 += 64u) {
+                    const uint32_t k = k0 + lane;
+                    bool keep = false;
+                    uint32_t code = 0;
+                    if (k < n_alive) {
+                        code = sC[wave][k];
+                        const uint32_t cell = code >> 1, odd = code & 1u;
+                        const uint32_t va = (cell >> 3) * kBlockVerts + (cell & 7u);
+                        const int2 q0 = sXY[wave][odd ? va + 1u : va], q1 = sXY[wave][va + kBlockVerts], q2 = sXY[wave][odd ? va + kBlockVerts + 1u : va + 1u];
+                        keep = classify_alive(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y VF_RC(, RC));
                     }
-                    const unsigned long long m0 = __ballot(k0 == 1), m1 = __ballot(k1 == 1);
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const uint32_t n0 = (uint32_t)__popcll(m0);
-                    if (k0 == 1) sS[wave][__popcll(m0 & below)] = (uint8_t)(2u * lane);
-                    if (k1 == 1) sS[wave][n0 + __popcll(m1 & below)] = (uint8_t)(2u * lane + 1u);
-                    nsurv = n0 + (uint32_t)__popcll(m1);
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) sS[wave][nsurv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)code;
+                    nsurv += (uint32_t)__popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
                 VF_RC(if (lane == 0) { rc_nsurv += nsurv; rc_live++; rc_empty += nsurv ? 0u : 1u; })
@@ -1111,8 +1254,8 @@ next_item:
                             const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                            raster_fast(T, prim + 1u, sX[wave][v0], sY[wave][v0], sX[wave][v1], sY[wave][v1], sX[wave][v2], sY[wave][v2],
-                                        (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
+                            const int2 q0 = sXY[wave][v0], q1 = sXY[wave][v1], q2 = sXY[wave][v2];
+                            raster_fast(T, prim + 1u, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
                         }
                     }
                 }
@@ -1178,7 +1321,7 @@ next_item:
         if (px > T.px_hi || py > T.py_hi) continue;
         const uint32_t id = s_vis[vis_index(lx, ly)];
         const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-        rgba[o] = id ? shade_pixel<COMPLETE>(P, hblk, S, id - 1u, px, py) : P.clear_rgba;
+        rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
         if (WRITE_VIS) vis_out[o] = id;
     }
     VF_PH(7)
@@ -1221,6 +1364,37 @@ next_item:
         }
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagnostics: the fragment stage as a launch of its own (vf_terrain_debug_fragment_stage).  Visibility (H, W) u32 in HBM ->
+// RGBA8 through the same shade_pixel the tile kernel runs on its LDS tile: fs_main + sRGB store
+// (src/shaders/terrain.wgsl:69-91).  One thread per pixel, one 256-pixel row segment per workgroup; streaming, 4 B read +
+// 4 B written per pixel plus the heights of the visible primitives.
+// ---------------------------------------------------------------------------------------------
+template <bool CLIPPED>
+__global__ __launch_bounds__(256) void k_resolve(FrameParams P, SetupView V, const float *__restrict__ lut_linear,
+                                                 const float *__restrict__ thresh, const uint32_t *__restrict__ vis,
+                                                 uint32_t *__restrict__ rgba, uint32_t *__restrict__ covered)
+{
+    __shared__ float s_lut[256 * 3];
+    __shared__ float s_thr[256];
+    for (int k = threadIdx.x; k < 768; k += 256) s_lut[k] = lut_linear[k];
+    s_thr[threadIdx.x] = thresh[threadIdx.x];
+    __syncthreads();
+    const uint32_t segs = (P.W + 255u) / 256u;
+    const uint32_t py = blockIdx.x / segs, px = (blockIdx.x - py * segs) * 256u + threadIdx.x;
+    uint32_t id = 0;
+    if (px < P.W) {
+        const size_t o = (size_t)py * P.W + px;
+        id = vis[o];
+        const ShadeTables S = { s_lut, s_thr };
+        rgba[o] = id ? shade_pixel<CLIPPED>(P, V, S, id - 1u, (int32_t)px, (int32_t)py) : P.clear_rgba;
+    }
+    if (covered) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(id != 0u));
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(covered, n);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

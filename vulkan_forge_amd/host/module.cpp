@@ -11,6 +11,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,24 @@ vf_ctx *global_ctx()
     return ctx.c;
 }
 
+// PyO3's `&mut self` borrow (Threading): a method entered while another thread is inside one of the same object
+// raises RuntimeError("Already borrowed") instead of racing.  It matters here because render / read-back release the GIL:
+// per-handle state (plan sets, pinned read-back buffers, frame counters) is not synchronised below the C-ABI ("calls on one
+// handle are not re-entrant", include/vf_hip.h).
+class Borrow {
+public:
+    explicit Borrow(std::atomic<bool> &flag, const char *what = "Already borrowed") : f(flag)
+    {
+        bool expected = false;
+        if (!f.compare_exchange_strong(expected, true, std::memory_order_acquire)) throw std::runtime_error(what);
+    }
+    ~Borrow() { f.store(false, std::memory_order_release); }
+    Borrow(const Borrow &) = delete;
+    Borrow &operator=(const Borrow &) = delete;
+private:
+    std::atomic<bool> &f;
+};
+
 Vec3 v3(const std::tuple<float, float, float> &t) { return { std::get<0>(t), std::get<1>(t), std::get<2>(t) }; }
 
 // mat4_to_numpy, src/camera.rs:94-112: (4,4) float32 C-contiguous in mathematical (row, col) indexing
@@ -136,6 +155,7 @@ public:
     void set_camera_look_at(std::tuple<float, float, float> eye, std::tuple<float, float, float> target,
                             std::tuple<float, float, float> up, float fovy_deg, float znear, float zfar)
     {
+        Borrow b(busy);
         float aspect = (float)W / (float)H;
         validate_camera_params(v3(eye), v3(target), v3(up), fovy_deg, znear, zfar);
         view = look_at_rh(v3(eye), v3(target), v3(up));
@@ -152,17 +172,18 @@ public:
             throw py::type_error("argument 'height_r32f': expected a 2-D numpy.ndarray of float32");
         if (!(arr.flags() & py::array::c_style)) throw std::runtime_error("height must be C-contiguous float32[H,W]");
         uint32_t h = (uint32_t)arr.shape(0), w = (uint32_t)arr.shape(1);
+        Borrow b(busy);
         check(vf_terrain_set_height(t, static_cast<const float *>(arr.data()), w, h));
     }
 
-    void render_into(uint8_t *dst, uint32_t rows)
+    void render_into(uint8_t *dst, uint32_t rows)          // caller holds the borrow
     {
         py::gil_scoped_release nogil;
         int rc = vf_terrain_render(t, nullptr);
         if (rc == VF_OK) rc = vf_terrain_read_rgba(t, dst, 0, rows);
         if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
     }
-    std::vector<uint8_t> render_pixels()
+    std::vector<uint8_t> render_pixels()                    // caller holds the borrow
     {
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
@@ -174,6 +195,7 @@ public:
     // render_png, src/terrain/mod.rs:409-491, src/scene/mod.rs:278-335
     void render_png(const std::string &path)
     {
+        Borrow b(busy);
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
         if (rows != H) {                                       // band-sharded handle: its rows only, filtered on the host
@@ -195,6 +217,7 @@ public:
     // extension (not in the reference): the frame as (H, W, 4) uint8 without the PNG round trip
     py::array_t<uint8_t> render_rgba()
     {
+        Borrow b(busy);
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
         py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
@@ -204,6 +227,7 @@ public:
     // extension: visible primitive id + 1 per pixel of the last render (0 = background)
     py::array_t<uint32_t> debug_visibility()
     {
+        Borrow b(busy);
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
         py::array_t<uint32_t> a({ (py::ssize_t)rows, (py::ssize_t)W });
@@ -211,28 +235,31 @@ public:
         return a;
     }
     // extension: multi-GPU band ownership (DESIGN.md "Sharding")
-    void set_shard(uint32_t rank, uint32_t nranks, uint32_t band_h) { check(vf_terrain_set_shard(t, rank, nranks, band_h)); }
+    void set_shard(uint32_t rank, uint32_t nranks, uint32_t band_h) { Borrow b(busy); check(vf_terrain_set_shard(t, rank, nranks, band_h)); }
     // extension: "reference" = fs_main as coded; "spec_t32" = the documented-only stage (forward-difference normals + Reinhard)
     void set_shade_mode(const std::string &mode)
     {
+        Borrow b(busy);
         if (mode == "reference") check(vf_terrain_set_shade_mode(t, VF_SHADE_REFERENCE));
         else if (mode == "spec_t32") check(vf_terrain_set_shade_mode(t, VF_SHADE_SPEC_T32));
         else throw py::value_error("shade mode must be 'reference' or 'spec_t32'");
     }
     py::dict last_timings()
     {
+        Borrow b(busy);
         vf_timings tm;
         check(vf_terrain_timings(t, &tm));
         py::dict d;
         d["ranges_ms"] = tm.ranges_ms; d["plan_ms"] = tm.plan_ms; d["tile_ms"] = tm.tile_ms; d["total_ms"] = tm.total_ms;
-        d["blocks_rasterised"] = tm.blocks_rasterised; d["tiles"] = tm.tiles; d["frames"] = tm.frames;
+        d["blocks_rasterised"] = tm.blocks_rasterised; d["tiles"] = tm.tiles; d["frames"] = tm.frames; d["blocks_distinct"] = tm.blocks_distinct;
         return d;
     }
-    void enable_timing(bool on) { check(vf_terrain_enable_timing(t, on ? 1 : 0)); }
+    void enable_timing(bool on) { Borrow b(busy); check(vf_terrain_enable_timing(t, on ? 1 : 0)); }
 
     // src/terrain/mod.rs:537-546
     py::array_t<float> debug_uniforms_f32() const
     {
+        if (busy.load(std::memory_order_acquire)) throw std::runtime_error("Already mutably borrowed");   // a `&self` method, PyO3-style
         py::array_t<float> a(44);
         std::memcpy(a.mutable_data(), last.data(), 44 * sizeof(float));
         return a;
@@ -251,6 +278,7 @@ private:
     Mat4 view{}, proj{};
     Uniforms last{};
     std::string lut_format;
+    mutable std::atomic<bool> busy{false};
 };
 
 class TerrainSpike : public TerrainObject {
@@ -293,20 +321,29 @@ public:
         py::array arr = py::reinterpret_borrow<py::array>(heightmap);
         const bool f32 = arr.dtype().is(py::dtype::of<float>()), f64 = arr.dtype().is(py::dtype::of<double>());
         if (arr.ndim() != 2 || !(f32 || f64)) throw std::runtime_error(kind);
-        if (!(arr.flags() & py::array::c_style)) throw std::runtime_error("heightmap must be C-contiguous (row-major)");
+        // a non-contiguous float32 array fails the reference's f32 attempt and then its f64 downcast: the dtype message
+        // (src/lib.rs:351-372); only a non-contiguous float64 array reports the layout (:374-376)
+        if (!(arr.flags() & py::array::c_style)) throw std::runtime_error(f32 ? kind : "heightmap must be C-contiguous (row-major)");
         const uint32_t h = (uint32_t)arr.shape(0), w = (uint32_t)arr.shape(1);
         if (w == 0 || h == 0) throw std::runtime_error("heightmap cannot be empty");
-        if (!dem) check(vf_dem_create(global_ctx(), &dem));
-        if (f32) check(vf_dem_set_heights_f32(dem, static_cast<const float *>(arr.data()), w, h, exaggeration));
-        else check(vf_dem_set_heights_f64(dem, static_cast<const double *>(arr.data()), w, h, exaggeration));
-        has_terrain = true;
+        // staged: the uploaded terrain replaces the current one only when the whole call succeeds (src/lib.rs:409-416 assigns
+        // self.terrain last); the height range alone is stored before the colormap check, as in the reference (:394)
+        struct Staged {
+            vf_dem *d = nullptr;
+            ~Staged() { if (d) vf_dem_destroy(d); }
+        } fresh;
+        check(vf_dem_create(global_ctx(), &fresh.d));
+        if (f32) check(vf_dem_set_heights_f32(fresh.d, static_cast<const float *>(arr.data()), w, h, exaggeration));
+        else check(vf_dem_set_heights_f64(fresh.d, static_cast<const double *>(arr.data()), w, h, exaggeration));
         // TerrainMeta::compute_and_store_h_range (src/renderer.rs:26-30): 1-99 percentile clamp
         float p1 = 0, p99 = 1;
-        check(vf_dem_percentile_range(dem, &p1, &p99));
+        check(vf_dem_percentile_range(fresh.d, &p1, &p99));
         h_min = p1; h_max = std::fmax(p99, p1 + 1e-5f);
         bool known = false;
         for (const char *s : kSupported) known |= colormap == s;
         if (!known) throw std::runtime_error(unknown_colormap(colormap));    // after the range, like the reference (:398-407)
+        std::swap(dem, fresh.d);                                             // (the previous terrain, if any, is released by `fresh`)
+        has_terrain = true;
         terrain_colormap = colormap;
     }
     void need_terrain() const { if (!has_terrain) throw std::runtime_error("no terrain uploaded; call add_terrain() first"); }
@@ -391,6 +428,15 @@ py::tuple grid_generate(uint32_t nx, uint32_t nz, std::tuple<float, float> spaci
 }
 
 std::vector<std::string> colormap_supported() { return { "viridis", "magma", "terrain" }; }   // src/colormap/mod.rs:44-47
+// extension: the 256 x 1 RGBA8 texels the registry resolves a name to (src/colormap/mod.rs:50-56), for callers that drive the
+// C-ABI themselves (vf_terrain_create takes the bytes)
+py::array_t<uint8_t> colormap_rgba8(const std::string &name)
+{
+    const uint8_t *lut = resolve_lut(name);
+    py::array_t<uint8_t> a({ (py::ssize_t)256, (py::ssize_t)4 });
+    std::memcpy(a.mutable_data(), lut, 1024);
+    return a;
+}
 
 py::array_t<float> camera_look_at(std::tuple<float, float, float> eye, std::tuple<float, float, float> target,
                                   std::tuple<float, float, float> up)
@@ -530,6 +576,7 @@ PYBIND11_MODULE(_vulkan_forge, m)
     m.def("grid_generate", &grid_generate, py::arg("nx"), py::arg("nz"), py::arg("spacing") = std::make_tuple(1.0f, 1.0f),
           py::arg("origin") = "center");
     m.def("colormap_supported", &colormap_supported);
+    m.def("colormap_rgba8", &colormap_rgba8, py::arg("name"));
     m.def("_encode_png_rgba8", &py_encode_png, py::arg("rgba"));
     m.def("camera_look_at", &camera_look_at, py::arg("eye"), py::arg("target"), py::arg("up"));
     m.def("camera_perspective", &camera_perspective, py::arg("fovy_deg"), py::arg("aspect"), py::arg("znear"), py::arg("zfar"),
