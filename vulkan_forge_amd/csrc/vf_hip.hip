@@ -107,8 +107,7 @@ struct vf_terrain {
     // so they overlap the previous frame's tile kernel (which still reads the other set) instead of waiting for it.
     struct PlanState {
         PixelBox *ranges = nullptr;      // per block: conservative pixel rectangle (from the block's height bounds)
-        int2 *vxy = nullptr;             // per block 81 snapped vertices (k_block_setup)
-        float *vrw = nullptr;            // per block 81 x 1/w
+        VertexRec *vtx = nullptr;        // per block 81 x {X, Y, 1/w, h} (k_block_setup)
         BlockRec *recs = nullptr;        // per block: alive masks, exact pixel box
         ulonglong2 *gen = nullptr;       // per block: primitives that need the generic path (valid where the record says so)
         PixelBox *row_ranges = nullptr;  // per block row
@@ -120,9 +119,10 @@ struct vf_terrain {
         uint32_t *redo = nullptr;        // those items (indices into work)
         uint32_t *background = nullptr;  // per local tile: bit 0 = no block row reaches it; bits 8.. = log2 of the strips it is cut into
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later (+ [ntiles] = split quantum)
-        hipEvent_t planned = nullptr, drawn = nullptr;
+        hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
     } ps[2];
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;          // k_block_boxes -> k_plan -> k_plan_sort
+    hipStream_t side2 = nullptr;         // k_block_setup (needs the block boxes only): beside the plan chain, both under the previous frame
     uint32_t frame_no = 0;
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
@@ -295,8 +295,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     const size_t all_tiles = (size_t)t->ntx * t->nty;
     for (auto &S : t->ps) {
         A((void **)&S.ranges, t->nblocks * sizeof(PixelBox));
-        A((void **)&S.vxy, (size_t)t->nblocks * kBlockStride * sizeof(int2));
-        A((void **)&S.vrw, (size_t)t->nblocks * kBlockStride * sizeof(float));
+        A((void **)&S.vtx, (size_t)t->nblocks * kBlockStride * sizeof(VertexRec));
         A((void **)&S.recs, (size_t)t->nblocks * sizeof(BlockRec));
         A((void **)&S.gen, (size_t)t->nblocks * sizeof(ulonglong2));
         A((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
@@ -312,8 +311,11 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         if (err == hipSuccess) err = hipMemset(S.background, 0, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.boxed, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.set_up, hipEventDisableTiming);
     }
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side2, hipStreamNonBlocking);
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
@@ -346,12 +348,15 @@ void vf_terrain_destroy(vf_terrain *t)
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_rgba_scratch, t->d_diag };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
-        void *sp[] = { S.vxy, S.vrw, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
+        void *sp[] = { S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
         for (void *p : sp) if (p) (void)hipFree(p);
         if (S.planned) (void)hipEventDestroy(S.planned);
         if (S.drawn) (void)hipEventDestroy(S.drawn);
+        if (S.boxed) (void)hipEventDestroy(S.boxed);
+        if (S.set_up) (void)hipEventDestroy(S.set_up);
     }
     if (t->side) (void)hipStreamDestroy(t->side);
+    if (t->side2) (void)hipStreamDestroy(t->side2);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
     if (t->d_png) (void)hipFree(t->d_png);
@@ -384,7 +389,7 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
     if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
-    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     size_t bytes = (size_t)tw * th * sizeof(float);
     if ((size_t)t->tw * t->th != (size_t)tw * th || t->d_height != t->d_height_own) {
         float *fresh = nullptr;                            // allocate first: a failure leaves the handle as it was
@@ -408,7 +413,7 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
     // a frame still in flight (caller's stream, or the plan / height-cache kernels on the side stream) reads the axis tables
     // and the old texture: let it finish before either changes
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
-    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     t->d_height = dev_height;
     int rc = set_height_common(t, tw, th);
     if (rc != VF_OK) return rc;
@@ -438,7 +443,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->rendered = false;
     t->frames_since_reset = 0;
     // tile numbering changed: forget the scheduling feedback of the previous layout
-    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
@@ -480,7 +485,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
     t->rendered = false;
     t->frames_since_reset = 0;
-    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
@@ -625,11 +630,12 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
     hipLaunchKernelGGL(k_block_boxes, dim3(t->nb + 1), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi,
                        fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count);
-    // vertex stage + tile-independent culling, once per frame (streams ~1 KB per block into this frame's plan state)
-    {
-        const uint32_t wgs = std::min<uint32_t>((t->nblocks + kSetupWaves - 1) / kSetupWaves, 8u * (uint32_t)std::max(1, t->ctx->prop.multiProcessorCount));
-        hipLaunchKernelGGL(k_block_setup, dim3(wgs), dim3(64 * kSetupWaves), 0, side, P, t->d_hblk, S.ranges, S.vxy, S.vrw, S.recs, S.gen);
-    }
+    // vertex stage + tile-independent culling, once per frame (streams ~1.3 KB per block into this frame's plan state): needs the
+    // block boxes only, so it runs on a second stream beside k_plan / k_plan_sort -- all of them under the previous frame's tile kernel
+    VF_HIP_TRY(hipEventRecord(S.boxed, side));
+    VF_HIP_TRY(hipStreamWaitEvent(t->side2, S.boxed, 0));               // (orders it after S.drawn and the height cache too)
+    hipLaunchKernelGGL(k_block_setup, dim3(t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks)), dim3(kSetupThreads), 0, t->side2, P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen);
+    VF_HIP_TRY(hipEventRecord(S.set_up, t->side2));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
         if (fresh) {
@@ -647,6 +653,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     uint32_t *stats = t->timing ? t->d_stats : nullptr;
     const uint32_t nstats = (uint32_t)(4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32);   // zeroed by k_clear (no memset dispatch)
     VF_HIP_TRY(hipStreamWaitEvent(s, S.planned, 0));
+    VF_HIP_TRY(hipStreamWaitEvent(s, S.set_up, 0));
     // the previous frame may have been drawn on another stream of the caller's: it wrote the same output / statistics buffers
     if (t->last_stream && t->last_stream != s && t->rendered) VF_HIP_TRY(hipStreamWaitEvent(s, O.drawn, 0));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
@@ -659,7 +666,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         uint32_t *redo_count = S.work_count + 3;
         const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount), ntiles + kSplitBudget)),
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
-        const SetupView V = { S.vxy, S.vrw, t->d_hblk, S.recs, S.gen };
+        const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, redo_count, S.redo
         if (write_vis) {
@@ -701,7 +708,7 @@ static int render_visibility(vf_terrain *t)
     if (!t->d_rgba_scratch) VF_HIP_TRY(hipMalloc(&t->d_rgba_scratch, npx * sizeof(uint32_t)));
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    VF_HIP_TRY(hipStreamSynchronize(t->side));
+    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     float u_now[44], u_drawn[32];
     std::memcpy(u_now, t->u, sizeof u_now); std::memcpy(u_drawn, t->u_drawn, sizeof u_drawn);
     uint32_t *const out_now = t->d_rgba;
@@ -860,7 +867,7 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
     if (err == hipSuccess) err = hipEventCreate(&e1);
     const dim3 grid(((t->W + 255u) / 256u) * t->H), threads(256);
     const vf_terrain::PlanState &S = t->ps[(t->frame_no - 1u) & 1u];     // the set-up of the frame just rendered
-    const SetupView V = { S.vxy, S.vrw, t->d_hblk, S.recs, S.gen };
+    const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
     auto launch = [&](uint32_t *covered) {
         if (redo) hipLaunchKernelGGL((k_resolve<true>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
         else hipLaunchKernelGGL((k_resolve<false>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);

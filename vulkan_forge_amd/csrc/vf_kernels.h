@@ -215,99 +215,156 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
 // ---------------------------------------------------------------------------------------------
 // per frame: vs_main (src/shaders/terrain.wgsl:44-66) for every vertex of every block that can reach the target, once, and the
 // tile-independent part of primitive assembly / culling (src/terrain/pipeline.rs:124-132: front = CCW, cull back; clip to
-// 0 <= z <= w).  One wave per block at a time:
-//   1. 9 x 9 displaced heights (two coalesced loads from the cache) -> clip coordinates -> 24.8 snapped X, Y, 1/w and clip flags;
-//      X, Y (648 B) and 1/w (324 B) go to HBM for the tile kernel's raster and fragment stages;
-//   2. lane = cell: both primitives are classified -- dead (non-finite, outside near/far, not projectable, bounding box without a
-//      pixel centre of the target, back-facing or degenerate), generic (needs clipping / oversized) or alive;
-//   3. alive masks by ballot, exact union of the alive primitives' pixel boxes by wave reduction -> BlockRec.
-// Streaming: 324 B read, ~1 KB written per block.  The tile kernel then loads instead of recomputing -- each block is looked at
-// by 1.9 tiles on average, by 16 strips of a heavy tile on a multi-GPU rank -- and never touches a block without alive primitives.
+// 0 <= z <= w).  One 256-thread workgroup per segment of 16 blocks of a block row:
+//   1. the segment's 9 x 129 vertices, each once (neighbouring blocks share their edge columns): displaced height from the cache
+//      -> clip coordinates -> 24.8 snapped X, Y, 1/w and clip flags, kept in LDS;
+//   2. one wave per block, lane = cell: both primitives are classified -- dead (non-finite, outside near/far, not projectable,
+//      bounding box without a pixel centre of the target, back-facing or degenerate), generic (needs clipping / oversized) or alive;
+//      alive masks by ballot, exact union of the alive primitives' pixel boxes by wave reduction -> BlockRec;
+//   3. the block's 81 vertices as {X, Y, 1/w, h} records (1296 B, coalesced) for the tile kernel's raster and fragment stages.
+// Streaming: 324 B read, ~1.3 KB written per block.  The tile kernel then loads instead of recomputing -- each block is looked at by
+// 1.9 tiles on average, by up to 16 strips of a heavy tile on a multi-GPU rank -- and never touches a block without alive primitives.
+// It needs at most 64 vector registers and 21 KB of LDS: workgroups of the NEXT frame's set-up (side stream) fit on a CU beside the
+// tile kernel's workgroup and run in the issue slots it leaves idle.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSetupWaves = 4;
-__global__ __launch_bounds__(64 * kSetupWaves) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
-                                                                  const PixelBox *__restrict__ cons_boxes, int2 *__restrict__ vxy,
-                                                                  float *__restrict__ vrw, BlockRec *__restrict__ recs,
-                                                                  ulonglong2 *__restrict__ gen)
+constexpr int kSegBlocks = 16;                             // blocks of one block row per workgroup
+constexpr int kSegCols = kSegBlocks * kBlockCells + 1;     // 129 vertex columns
+constexpr int kSegStride = 136;                            // LDS row pitch (8-byte words): rows 16 banks apart, conflict-free cell reads
+constexpr int kSetupThreads = 256;
+struct VertexRec { int32_t X, Y; float rw, h; };           // 24.8 snapped position, 1/w, displaced height (the `height` varying)
+static_assert(sizeof(VertexRec) == 16, "VertexRec is moved as one 16-byte word");
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b)
 {
-    constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
-    __shared__ int32_t sX[kSetupWaves][kNV];
-    __shared__ int32_t sY[kSetupWaves][kNV];
-    __shared__ uint8_t sF[kSetupWaves][kNV + 3];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t nblocks = P.nb * P.nb;
-    for (uint32_t b = blockIdx.x * kSetupWaves + wave; b < nblocks; b += gridDim.x * kSetupWaves) {
+    const short2v r = __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+    const short2v r = __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+__global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
+                                                               const PixelBox *__restrict__ cons_boxes, VertexRec *__restrict__ vtx,
+                                                               BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen)
+{
+    __shared__ int2 sXY[kBlockVerts][kSegStride];
+    __shared__ float2 sWH[kBlockVerts][kSegStride];
+    __shared__ uint8_t sF[kBlockVerts][kSegStride];
+    __shared__ uint32_t s_on_target, s_flagged;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t segs = (P.nb + kSegBlocks - 1) / kSegBlocks;
+    const uint32_t by = blockIdx.x / segs, bx0 = (blockIdx.x - by * segs) * kSegBlocks;
+    const uint32_t nblk = min((uint32_t)kSegBlocks, P.nb - bx0);
+    const uint32_t b0 = by * P.nb + bx0;
+    if (tid == 0) { s_on_target = 0u; s_flagged = 0u; }
+    __syncthreads();
+    if (tid < nblk) { const PixelBox cb = cons_boxes[b0 + tid]; if (cb.x0 <= cb.x1) s_on_target = 1u; }
+    __syncthreads();
+    if (!s_on_target) {                                    // (uniform) the whole segment is clipped away or off the target
+        if (tid < nblk) {
+            BlockRec rec;
+            rec.box = PixelBox{ 1, 1, 0, 0 }; rec.flags = 0u; rec.count = 0u; rec.alive_even = 0ull; rec.alive_odd = 0ull;
+            recs[b0 + tid] = rec;
+        }
+        return;
+    }
+    // ---- 1. vertex stage: 9 rows x (8 nblk + 1) columns, every vertex once ----
+    const uint32_t i0 = bx0 * kBlockCells, j0 = by * kBlockCells, ncols = nblk * kBlockCells + 1u;
+    bool flagged = false;
+    for (uint32_t v = tid; v < (uint32_t)(kBlockVerts * kSegCols); v += kSetupThreads) {
+        const uint32_t r = v / (uint32_t)kSegCols, c = v - r * (uint32_t)kSegCols;
+        if (c >= ncols) continue;
+        const uint32_t i = i0 + c, j = j0 + r;
+        int32_t X = 0, Y = 0;
+        float rw = 0.0f, h = 0.0f;
+        uint32_t fl = F_BAD;
+        if (i < P.n && j < P.n) {
+            const uint32_t k = min(c >> 3, nblk - 1u);    // the cache is per block: column 8 k' is also column 8 of block k' - 1
+            h = hblk[(size_t)(b0 + k) * kBlockStride + r * kBlockVerts + (c - 8u * k)];
+            const ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), h);
+            fl = vertex_flags(cv);
+            if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
+        }
+        flagged |= fl != 0u && i < P.n && j < P.n;
+        sXY[r][c] = make_int2(X, Y); sWH[r][c] = make_float2(rw, h); sF[r][c] = (uint8_t)fl;
+    }
+    if (__any(flagged) && lane == 0) s_flagged = 1u;
+    __syncthreads();
+    const bool any_flag = s_flagged != 0u;                 // (uniform) false for every ordinary view: the flag tests drop out
+    // ---- 2./3. one wave per block ----
+    for (uint32_t k = wave; k < nblk; k += kSetupThreads / 64) {
+        const uint32_t b = b0 + k, cbase = k * kBlockCells;
         const PixelBox cb = cons_boxes[b];                 // conservative box of the block's height bounds (k_block_boxes)
         BlockRec rec;
         rec.box = PixelBox{ 1, 1, 0, 0 }; rec.flags = 0u; rec.count = 0u; rec.alive_even = 0ull; rec.alive_odd = 0ull;
-        if (cb.x0 > cb.x1) {                               // (uniform) clipped away or off the target: nothing to set up
+        if (cb.x0 > cb.x1) {                               // (uniform) clipped away or off the target: nothing to draw
             if (lane == 0) recs[b] = rec;
             continue;
         }
-        const uint32_t bx = b % P.nb, by = b / P.nb;
-        const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
-        const float *hb = hblk + (size_t)b * kBlockStride;
-        for (int v = lane; v < kNV; v += 64) {
-            const uint32_t lj = v / kBlockVerts, li = v - lj * kBlockVerts;
-            const uint32_t i = i0 + li, j = j0 + lj;
-            int32_t X = 0, Y = 0;
-            float rw = 0.0f;
-            uint32_t fl = F_BAD;
-            if (i < P.n && j < P.n) {
-                ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), hb[v]);
-                fl = vertex_flags(cv);
-                if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
-            }
-            sX[wave][v] = X; sY[wave][v] = Y; sF[wave][v] = (uint8_t)fl;
-            vxy[(size_t)b * kBlockStride + v] = make_int2(X, Y);
-            vrw[(size_t)b * kBlockStride + v] = rw;
+        // the block's 81 vertex records, 16 bytes per lane
+        for (uint32_t v = lane; v < (uint32_t)(kBlockVerts * kBlockVerts); v += 64u) {
+            const uint32_t r = v / (uint32_t)kBlockVerts, li = v - r * (uint32_t)kBlockVerts;
+            const int2 xy = sXY[r][cbase + li];
+            const float2 wh = sWH[r][cbase + li];
+            VertexRec o;
+            o.X = xy.x; o.Y = xy.y; o.rw = wh.x; o.h = wh.y;
+            vtx[(size_t)b * kBlockStride + v] = o;
         }
-        __builtin_amdgcn_wave_barrier();
         // lane = cell
         const uint32_t lj = lane >> 3, li = lane & 7u;
         int c0 = 0, c1 = 0;                                // 0 dead, 1 alive, 2 generic
-        int32_t bx0 = 0x7FFF, by0 = 0x7FFF, bx1 = -1, by1 = -1;
-        if (i0 + li < P.nm1 && j0 + lj < P.nm1) {
-            const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
-            const int32_t Xa = sX[wave][va], Ya = sY[wave][va], Xb = sX[wave][vb], Yb = sY[wave][vb];
-            const int32_t Xc = sX[wave][vc], Yc = sY[wave][vc], Xd = sX[wave][vd], Yd = sY[wave][vd];
-            const uint32_t fa = sF[wave][va], fb = sF[wave][vb], fc = sF[wave][vc], fd = sF[wave][vd];
-            auto classify = [&](uint32_t f0, uint32_t f1, uint32_t f2, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2) -> int {
-                const uint32_t any = f0 | f1 | f2, all = f0 & f1 & f2;
-                if (any & F_BAD) return 0;                            // non-finite clip coordinate: primitive dropped
-                if (all & (F_NEAR | F_FAR)) return 0;                 // entirely outside the near or the far plane
-                if (any & (F_NEAR | F_FAR)) return 2;                 // needs clipping
-                if (any & F_NOSNAP) return 0;                         // a vertex could not be projected (w <= 0)
-                const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
-                const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-                if ((uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kFastExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kFastExtent) return 2;
+        uint32_t lo = 0x7FFF7FFFu, hi = 0x80008000u;       // packed (x, y) int16: running min of (px0, py0), max of (px1, py1)
+        if (i0 + cbase + li < P.nm1 && j0 + lj < P.nm1) {
+            const int2 pa = sXY[lj][cbase + li], pb = sXY[lj][cbase + li + 1u], pc = sXY[lj + 1u][cbase + li], pd = sXY[lj + 1u][cbase + li + 1u];
+            uint32_t fa = 0, fb = 0, fc = 0, fd = 0;
+            if (any_flag) { fa = sF[lj][cbase + li]; fb = sF[lj][cbase + li + 1u]; fc = sF[lj + 1u][cbase + li]; fd = sF[lj + 1u][cbase + li + 1u]; }
+            // Straight-line on purpose: nearly every primitive reaches the facing test, so early exits would only add divergent
+            // branches (scalar instructions cost twice a vector one here); the flag tests are skipped as a whole in ordinary views.
+            auto classify = [&](uint32_t f0, uint32_t f1, uint32_t f2, int2 q0, int2 q1, int2 q2) -> int {
+                int forced = -1;                                       // a verdict from the clip flags, if any
+                if (any_flag) {
+                    const uint32_t any = f0 | f1 | f2, all = f0 & f1 & f2;
+                    if (any & F_BAD) forced = 0;                      // non-finite clip coordinate: primitive dropped
+                    else if (all & (F_NEAR | F_FAR)) forced = 0;      // entirely outside the near or the far plane
+                    else if (any & (F_NEAR | F_FAR)) forced = 2;      // needs clipping
+                    else if (any & F_NOSNAP) forced = 0;              // a vertex could not be projected (w <= 0)
+                }
+                const int32_t xmin = min(q0.x, min(q1.x, q2.x)), xmax = max(q0.x, max(q1.x, q2.x));
+                const int32_t ymin = min(q0.y, min(q1.y, q2.y)), ymax = max(q0.y, max(q1.y, q2.y));
+                const bool oversized = (uint32_t)xmax - (uint32_t)xmin >= (uint32_t)kFastExtent || (uint32_t)ymax - (uint32_t)ymin >= (uint32_t)kFastExtent;
                 const int32_t px0 = max((xmin + 127) >> 8, 0), px1 = min((xmax - 128) >> 8, (int32_t)P.W - 1);
                 const int32_t py0 = max((ymin + 127) >> 8, 0), py1 = min((ymax - 128) >> 8, (int32_t)P.H - 1);
-                if (px0 > px1 || py0 > py1) return 0;                 // no pixel centre of the target inside the bounding box
-                const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
-                if (area2 >= 0) return 0;                             // back-facing or degenerate
-                bx0 = min(bx0, px0); by0 = min(by0, py0); bx1 = max(bx1, px1); by1 = max(by1, py1);
-                return 1;
+                const bool holds_centre = px0 <= px1 && py0 <= py1;    // a pixel centre of the target inside the bounding box
+                // facing: extents < 2^24 (else oversized), so both products are exact in FP64 and so is their difference (an int64
+                // multiply-add costs four times the issue cycles on this chip)
+                const double area2 = fma((double)(q1.x - q0.x), (double)(q2.y - q0.y), -((double)(q1.y - q0.y) * (double)(q2.x - q0.x)));
+                const bool alive = forced < 0 && !oversized && holds_centre && area2 < 0.0;   // front-facing, not degenerate
+                const uint32_t plo = (uint32_t)px0 | ((uint32_t)py0 << 16), phi = (uint32_t)px1 | ((uint32_t)py1 << 16);
+                lo = alive ? pk_min_i16(lo, plo) : lo;
+                hi = alive ? pk_max_i16(hi, phi) : hi;
+                return forced >= 0 ? forced : (oversized ? 2 : (alive ? 1 : 0));
             };
-            c0 = classify(fa, fc, fb, Xa, Ya, Xc, Yc, Xb, Yb);        // (a, c, b)
-            c1 = classify(fb, fc, fd, Xb, Yb, Xc, Yc, Xd, Yd);        // (b, c, d)
+            c0 = classify(fa, fc, fb, pa, pc, pb);        // (a, c, b)
+            c1 = classify(fb, fc, fd, pb, pc, pd);        // (b, c, d)
         }
         const unsigned long long a0 = __ballot(c0 == 1), a1 = __ballot(c1 == 1), g0 = __ballot(c0 == 2), g1 = __ballot(c1 == 2);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
-            bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
+            lo = pk_min_i16(lo, (uint32_t)__shfl_xor((int)lo, o));
+            hi = pk_max_i16(hi, (uint32_t)__shfl_xor((int)hi, o));
         }
         rec.alive_even = a0; rec.alive_odd = a1;
         rec.count = (uint32_t)(__popcll(a0) + __popcll(a1));
         if (g0 | g1) { rec.flags = kRecGeneric; rec.box = cb; }      // generic primitives: only the conservative bound holds
-        else if (rec.count) rec.box = PixelBox{ (int16_t)bx0, (int16_t)by0, (int16_t)bx1, (int16_t)by1 };
+        else if (rec.count) rec.box = PixelBox{ (int16_t)(lo & 0xFFFFu), (int16_t)(lo >> 16), (int16_t)(hi & 0xFFFFu), (int16_t)(hi >> 16) };
         if (lane == 0) {
             recs[b] = rec;
             if (g0 | g1) gen[b] = make_ulonglong2(g0, g1);
         }
-        __builtin_amdgcn_wave_barrier();                    // the next block reuses this wave's LDS slot
     }
 }
 
@@ -592,9 +649,8 @@ __device__ __forceinline__ bool vertex_plain(const GVert &v) { return finite4(v.
 
 // What the fragment stage needs of the frame's set-up (k_block_setup): snapped vertices, 1/w, displaced heights, block records.
 struct SetupView {
-    const int2 *vxy;            // per block 81 x (X, Y), 24.8 fixed point
-    const float *vrw;           // per block 81 x 1/w
-    const float *hblk;          // per block 81 displaced heights (the `height` varying)
+    const VertexRec *vtx;       // per block 81 x {X, Y (24.8 fixed point), 1/w, displaced height}
+    const float *hblk;          // per block 81 displaced heights (generic path: the vertex stage is run again there)
     const BlockRec *recs;
     const ulonglong2 *gen;      // per block: which primitives need the generic path (valid where kRecGeneric is set)
 };
@@ -627,15 +683,14 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V,
     const uint32_t va = lj * kBlockVerts + li;
     const uint32_t l0 = odd ? va + 1u : va, l1 = va + kBlockVerts, l2 = odd ? va + kBlockVerts + 1u : va + 1u;
     const size_t base = b * kBlockStride;
-    const int2 p0 = V.vxy[base + l0], p1 = V.vxy[base + l1], p2 = V.vxy[base + l2];
-    const float rw0 = V.vrw[base + l0], rw1 = V.vrw[base + l1], rw2 = V.vrw[base + l2];
-    const float h0 = V.hblk[base + l0], h1 = V.hblk[base + l1], h2 = V.hblk[base + l2];
+    const VertexRec r0 = V.vtx[base + l0], r1 = V.vtx[base + l1], r2 = V.vtx[base + l2];   // three 16-byte loads: all a vertex contributes
+    const float rw0 = r0.rw, rw1 = r1.rw, rw2 = r2.rw, h0 = r0.h, h1 = r1.h, h2 = r2.h;
     // varyings xz (terrain.wgsl:64): vertex 0 = (i + odd, j), vertex 1 = (i, j + 1), vertex 2 = (i + 1, j + odd)
     const float x0 = grid_coord(P, i + odd), x1 = grid_coord(P, i), x2 = grid_coord(P, i + 1u);
     const float z0 = grid_coord(P, j), z1 = grid_coord(P, j + 1u), z2 = grid_coord(P, j + odd);
     // inside-positive edge weights at the pixel centre (covers() / edge_fn() in int64, here exactly the same values in FP64)
     const double Px = (double)(px * 256 + 128), Py = (double)(py * 256 + 128);
-    const double X0 = p0.x, Y0 = p0.y, X1 = p1.x, Y1 = p1.y, X2 = p2.x, Y2 = p2.y;
+    const double X0 = r0.X, Y0 = r0.Y, X1 = r1.X, Y1 = r1.Y, X2 = r2.X, Y2 = r2.Y;
     const double e0 = -fma(X2 - X1, Py - Y1, -((Y2 - Y1) * (Px - X1)));
     const double e1 = -fma(X0 - X2, Py - Y2, -((Y0 - Y2) * (Px - X2)));
     const double e2 = -fma(X1 - X0, Py - Y0, -((Y1 - Y0) * (Px - X0)));
@@ -1168,13 +1223,24 @@ next_item:
             if (idx >= nlist) break;
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
+            // One round trip for everything the block needs from HBM: its record (pixel box, alive masks) and its 81 snapped
+            // vertices are requested together, before the box decides whether the block is still worth drawing -- a dependent
+            // second trip costs a wave more than the vertices of the blocks that turn out culled.
+            const uint32_t bidx = by * P.nb + bx;
+            const uint4 *recw = reinterpret_cast<const uint4 *>(V.recs + bidx);     // (wave-uniform address)
+            const uint4 r_lo = recw[0], r_hi = recw[1];            // box (2 words), flags, count | alive_even, alive_odd
+            const uint4 *vsrc = reinterpret_cast<const uint4 *>(V.vtx + (size_t)bidx * kBlockStride);
+            const uint4 va4 = vsrc[lane];
+            uint4 vb4 = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < (uint32_t)(kNV - 64)) vb4 = vsrc[64u + lane];
+            const int2 xa = make_int2((int32_t)va4.x, (int32_t)va4.y), xb = make_int2((int32_t)vb4.x, (int32_t)vb4.y);   // the raster needs X, Y only
             // late culling against the masks published since the list was built (one column / row per lane)
-            const BlockRec *rec = V.recs + (by * P.nb + bx);         // (wave-uniform address)
             bool live;
             {
-                const PixelBox b = rec->box;
-                const int32_t x0 = max((int32_t)b.x0, T.px_lo) - T.px_lo, x1 = min((int32_t)b.x1, T.px_hi) - T.px_lo;
-                const int32_t y0 = max((int32_t)b.y0, T.py_lo) - T.py_lo, y1 = min((int32_t)b.y1, T.py_hi) - T.py_lo;
+                const int32_t bx0 = (int32_t)(int16_t)(r_lo.x & 0xFFFFu), by0 = (int32_t)(int16_t)(r_lo.x >> 16);
+                const int32_t bx1 = (int32_t)(int16_t)(r_lo.y & 0xFFFFu), by1 = (int32_t)(int16_t)(r_lo.y >> 16);
+                const int32_t x0 = max(bx0, T.px_lo) - T.px_lo, x1 = min(bx1, T.px_hi) - T.px_lo;
+                const int32_t y0 = max(by0, T.py_lo) - T.py_lo, y1 = min(by1, T.py_hi) - T.py_lo;
                 const bool in = (int32_t)lane >= x0 && (int32_t)lane <= x1;
                 const uint64_t open = in ? (~load_mask(s_colfin, (int32_t)lane) & bit_range(y0, y1)) : 0ull;
                 live = __ballot(open != 0ull) != 0ull;
@@ -1182,22 +1248,15 @@ next_item:
             VF_PH(1)
             if (live) {
                 ++my_blocks;
-                if (stats && lane == 0) {                  // diagnostics: which blocks were drawn by at least one tile this frame
-                    const uint32_t bi = by * P.nb + bx;
-                    atomicOr(&stats[4u + 4u * (P.ntx * P.nty + kSplitBudget) + 2u * kPhaseSlots + (bi >> 5)], 1u << (bi & 31u));
-                }
+                if (stats && lane == 0)                    // diagnostics: which blocks were drawn by at least one tile this frame
+                    atomicOr(&stats[4u + 4u * (P.ntx * P.nty + kSplitBudget) + 2u * kPhaseSlots + (bidx >> 5)], 1u << (bidx & 31u));
                 const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
                 // ---- set-up stage, once per frame in k_block_setup: here the block's snapped vertices and alive masks are loads ----
-                const unsigned long long alive_e = rec->alive_even, alive_o = rec->alive_odd;
-                const uint32_t rflags = rec->flags;
-                {
-                    const int2 *src = V.vxy + (size_t)(by * P.nb + bx) * kBlockStride;
-                    const int2 xa = src[lane];
-                    int2 xb = make_int2(0, 0);
-                    if (lane < (uint32_t)(kNV - 64)) xb = src[64u + lane];
-                    sXY[wave][lane] = xa;
-                    if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
-                }
+                const unsigned long long alive_e = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.x) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.y) << 32);
+                const unsigned long long alive_o = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.z) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.w) << 32);
+                const uint32_t rflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_lo.z);
+                sXY[wave][lane] = xa;
+                if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
                 if (!COMPLETE && (rflags & kRecGeneric)) { if (lane == 0) s_redo = 1u; }   // rare: clipped / oversized -> the COMPLETE launch
                 // the alive primitives as a dense list: cell c's even primitive sits at popcount(alive_e below c), its odd one behind all
                 // the even ones -- every lane of the classification below then holds a primitive that can draw
@@ -1212,7 +1271,7 @@ next_item:
                 VF_PH(2)
                 if constexpr (COMPLETE) if (rflags & kRecGeneric) {
                     // lane = cell: the primitives k_block_setup marked generic go through clipping and the per-pixel int64 test
-                    const ulonglong2 g = V.gen[by * P.nb + bx];
+                    const ulonglong2 g = V.gen[bidx];
                     const uint32_t lj = lane >> 3, li = lane & 7u;
                     const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li));
                     GVert gv[3];                                               // in memory only on this rare path
