@@ -22,6 +22,7 @@
 // block row r: after a block row has been rasterised, covered pixels are final.
 #pragma once
 #include "vf_device.h"
+#include "vf_raster.h"
 
 namespace vf {
 
@@ -389,15 +390,12 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
     return (~0ull >> (63 - (hi - lo))) << lo;
 }
 
-// Exact rasterisation of one unclipped triangle restricted to the tile.
-// Edge functions are evaluated in FP64: all operands are integers < 2^25 and every product/sum stays
-// below 2^53, so the arithmetic is exact.  For each line of the shorter bbox axis the covered span
-// along the longer axis is bounded by the three half-planes alpha_i + beta_i * r > 0; the crossing is
-// estimated in FP32 (error < 1/4 for quotients < 2^20, larger ones are clamped away) and then fixed up
-// with the exact FP64 edge value, so the span is exactly the set of covered pixel centres.  The estimate
-// stage, which five lines in six do not survive, uses only the two edges that span the most lines.
-// Lines whose candidate pixels are all final (owned by a higher block row) are skipped unsolved, and
-// only non-final pixels are touched.
+// Exact rasterisation of one unclipped, front-facing triangle restricted to the tile: for each line of the SHORTER bbox axis the
+// covered span along the longer one, by the span solver of vf_raster.h -- three FP32 crossings with a proven error bound decide
+// nearly every line (stage 1: a span that contains the true one, rejected if it holds no open pixel -- five lines in six of the
+// sub-pixel-wide slivers a noise terrain is made of; stage 2: no pixel centre within the error of a crossing => that span is exact),
+// and the rare line they cannot decide is solved in FP64 on the integer coordinates.  Lines whose candidate pixels are all final
+// (owned by a higher block row) are skipped unsolved, and only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
 #ifdef VF_PHASE_PROF
 struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach; };
@@ -414,89 +412,53 @@ __device__ __forceinline__ int32_t floor_to_int(float x)
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(x));
     return k;
 }
-__device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1,
-                                            int32_t X2, int32_t Y2, int32_t sub, int32_t nsub VF_RC_ARG)
+// `vb` / `vcode`: where the three vertices came from (this wave's LDS copy of the block, local indices v0 | v1 << 8 | v2 << 16): the
+// exact solver reloads them from there instead of keeping six more registers alive through the line loop for a rare event.
+__device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, const int2 *vb, uint32_t vcode, int32_t sub, int32_t nsub VF_RC_ARG)
 {
     VF_RC(RC.tris++;)
-    const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
-    const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-    const int32_t px0 = max((xmin + 127) >> 8, T.px_lo), px1 = min((xmax - 128) >> 8, T.px_hi);
-    const int32_t py0 = max((ymin + 127) >> 8, T.py_lo), py1 = min((ymax - 128) >> 8, T.py_hi);
-    if (px0 > px1 || py0 > py1) return;
-    const bool cols = (px1 - px0) <= (py1 - py0);          // iterate the short axis, solve spans along the long one
-    {   // Rotate the vertices so that edge 2 (v0 -> v1) is the one that spans the fewest lines: the estimate stage below leaves
-        // it out -- it only ever trims a line's span near one end of the triangle -- and the exact stage still applies it.
-        const int32_t c0 = cols ? X0 : Y0, c1 = cols ? X1 : Y1, c2 = cols ? X2 : Y2;
-        const int32_t e0 = abs(c2 - c1), e1 = abs(c0 - c2), e2 = abs(c1 - c0);
-        const bool left = e0 < e2 && e0 <= e1, right = !left && e1 < e2;      // (v1, v2, v0) / (v2, v0, v1): same orientation
-        const int32_t x0 = X0, y0 = Y0;
-        if (left) { X0 = X1; Y0 = Y1; X1 = X2; Y1 = Y2; X2 = x0; Y2 = y0; }
-        else if (right) { X0 = X2; Y0 = Y2; X2 = X1; Y2 = Y1; X1 = x0; Y1 = y0; }
+    int32_t px0, py0, n_outer, n_inner, o_base, i_base;
+    bool cols;
+    SpanSetup S;
+    {
+        const int2 q0 = vb[vcode & 0xFFu], q1 = vb[(vcode >> 8) & 0xFFu], q2 = vb[vcode >> 16];
+        const int32_t xmin = min(q0.x, min(q1.x, q2.x)), xmax = max(q0.x, max(q1.x, q2.x));
+        const int32_t ymin = min(q0.y, min(q1.y, q2.y)), ymax = max(q0.y, max(q1.y, q2.y));
+        px0 = max((xmin + 127) >> 8, T.px_lo); py0 = max((ymin + 127) >> 8, T.py_lo);
+        const int32_t px1 = min((xmax - 128) >> 8, T.px_hi), py1 = min((ymax - 128) >> 8, T.py_hi);
+        if (px0 > px1 || py0 > py1) return;
+        cols = (px1 - px0) <= (py1 - py0);                 // iterate the short axis, solve spans along the long one
+        const int32_t U[3] = { cols ? q0.x : q0.y, cols ? q1.x : q1.y, cols ? q2.x : q2.y };     // outer / inner coordinates of the vertices
+        const int32_t V[3] = { cols ? q0.y : q0.x, cols ? q1.y : q1.x, cols ? q2.y : q2.x };
+        n_outer = cols ? px1 - px0 : py1 - py0; n_inner = cols ? py1 - py0 : px1 - px0;
+        span_setup(U, V, !cols, (cols ? px0 : py0) * 256 + 128, (cols ? py0 : px0) * 256 + 128, n_outer, S);
     }
-    const double dX0 = X0, dY0 = Y0, dX1 = X1, dY1 = Y1, dX2 = X2, dY2 = Y2;
-    const double area2 = fma(dX1 - dX0, dY2 - dY0, -((dY1 - dY0) * (dX2 - dX0)));
-    if (area2 >= 0.0) return;                              // back-facing or degenerate
-    const int32_t n_outer = cols ? px1 - px0 : py1 - py0, n_inner = cols ? py1 - py0 : px1 - px0;
-    const int32_t o_base = cols ? px0 - T.px_lo : py0 - T.py_lo;     // tile-local index of outer line 0
-    const int32_t i_base = cols ? py0 - T.py_lo : px0 - T.px_lo;     // tile-local index of inner offset 0
+    o_base = cols ? px0 - T.px_lo : py0 - T.py_lo;         // tile-local index of outer line 0
+    i_base = cols ? py0 - T.py_lo : px0 - T.px_lo;         // tile-local index of inner offset 0
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
-    const uint64_t seg = bit_range(i_base, i_base + n_inner);
-    // inside-positive edge functions e_i(P) = A_i (Px - Xr_i) + B_i (Py - Yr_i); covered iff e_i + t_i > 0
-    const double A[3] = { dY2 - dY1, dY0 - dY2, dY1 - dY0 };
-    const double B[3] = { -(dX2 - dX1), -(dX0 - dX2), -(dX1 - dX0) };
-    const double XR[3] = { dX1, dX2, dX0 }, YR[3] = { dY1, dY2, dY0 };
-    // f_i(o, r) = base_i + SO_i*o + SI_i*r   with o/r = outer/inner pixel offsets from (px0, py0)
-    double base[3], SO[3], SI[3];
-    float rSI[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double tl = (A[i] > 0.0 || (A[i] == 0.0 && B[i] > 0.0)) ? 1.0 : 0.0;
-        base[i] = fma(A[i], (double)(px0 * 256 + 128) - XR[i], fma(B[i], (double)(py0 * 256 + 128) - YR[i], tl));
-        SO[i] = 256.0 * (cols ? A[i] : B[i]);
-        SI[i] = 256.0 * (cols ? B[i] : A[i]);
-        rSI[i] = SI[i] != 0.0 ? __builtin_amdgcn_rcpf((float)SI[i]) : 0.0f;   // 1 ulp is plenty: only the estimate uses it
-    }
-    const float q_lo = -4.0f, q_hi = (float)(n_inner + 4);
     for (int32_t o = sub; o <= n_outer; o += nsub) {
         const uint64_t done = load_mask(fin, o_base + o);
-        const uint64_t open = ~done & seg;
         VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;)
-        if (open == 0ull) continue;
-        VF_RC(RC.trips++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s1++;)
-        // ---- stage 1: conservative span from FP32 crossing estimates (exact alpha, relative error ~2^-22 => |error| < 1/4
-        //      inside the clamp range): true lo is one of k, k+1, k+2; true hi one of k+1, k, k-1, k-2 ----
-        double alpha[3];
-        int32_t kk[3];
-        int32_t lo_a = 0, hi_a = n_inner;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {                             // (edges 0 and 1: the two that span the most lines)
-            alpha[i] = fma(SO[i], (double)o, base[i]);            // f_i at inner offset 0 (exact)
-            kk[i] = floor_to_int(__builtin_amdgcn_fmed3f(-(float)alpha[i] * rSI[i], q_lo, q_hi));   // clamp in one instruction (q_lo < q_hi)
-            if (SI[i] > 0.0) lo_a = max(lo_a, kk[i]);
-            else if (SI[i] < 0.0) hi_a = min(hi_a, kk[i] + 1);
-            else if (alpha[i] <= 0.0) hi_a = -1;
-        }
-        if (lo_a > hi_a) continue;
-        if ((bit_range(i_base + lo_a, i_base + hi_a) & open) == 0ull) continue;   // nothing this line could still change
-        // ---- stage 2: exact fix-up with g(r) = alpha + beta*r in FP64 ----
+        // ---- stage 1 (straight-line): a span that contains the true one; does it hold an open pixel? ----
+        int32_t F[3], lo, hi;
+        span_line(S, o, n_inner, F, lo, hi);
+        if (!S.regular) { lo = 0; hi = n_inner; }          // (rare) no FP32 form for this triangle: every open line goes to the exact solver
+        const uint64_t cand = bit_range(i_base + min(lo, n_inner), i_base + max(hi, 0)) & ~done;   // (garbage when lo > hi: tested first)
+        VF_RC(if (~done) { RC.trips++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s1++; })
+        if (lo > hi || cand == 0ull) continue;             // nothing this line could still change
+        // ---- stage 2: the span is exact unless a pixel centre lies within the FP32 error of a crossing ----
         VF_RC(RC.solved++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_s2++;)
-        alpha[2] = fma(SO[2], (double)o, base[2]);
-        kk[2] = floor_to_int(__builtin_amdgcn_fmed3f(-(float)alpha[2] * rSI[2], q_lo, q_hi));
-        int32_t lo = 0, hi = n_inner;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double beta = SI[i];
-            if (beta > 0.0) {            // smallest r with g(r) > 0
-                const double g0 = fma(beta, (double)kk[i], alpha[i]);
-                lo = max(lo, kk[i] + (g0 <= 0.0 ? ((g0 + beta) <= 0.0 ? 2 : 1) : 0));
-            } else if (beta < 0.0) {     // largest r with g(r) > 0
-                const double g1 = fma(beta, (double)(kk[i] + 1), alpha[i]);
-                const double g0 = g1 - beta, gm = g0 - beta;
-                hi = min(hi, g1 > 0.0 ? kk[i] + 1 : (g0 > 0.0 ? kk[i] : (gm > 0.0 ? kk[i] - 1 : kk[i] - 2)));
-            } else if (alpha[i] <= 0.0) hi = -1;
+        uint64_t bits = cand;
+        if (!S.regular || !span_confirm(S, o, n_inner, F)) {
+            // (about one line in 10^4) exact: from the integer coordinates, reloaded -- nothing of this is kept or hoisted out of the loop
+            asm volatile("" ::: "memory");
+            const int2 q0 = vb[vcode & 0xFFu], q1 = vb[(vcode >> 8) & 0xFFu], q2 = vb[vcode >> 16];
+            const int32_t U[3] = { cols ? q0.x : q0.y, cols ? q1.x : q1.y, cols ? q2.x : q2.y };
+            const int32_t V[3] = { cols ? q0.y : q0.x, cols ? q1.y : q1.x, cols ? q2.y : q2.x };
+            span_exact(U, V, !cols, (cols ? px0 : py0) * 256 + 128, (cols ? py0 : px0) * 256 + 128, o, n_inner, lo, hi);
+            if (lo > hi) continue;
+            bits = bit_range(i_base + lo, i_base + hi) & ~done;
         }
-        if (lo > hi) continue;
-        uint64_t bits = bit_range(i_base + lo, i_base + hi) & ~done;
         const int32_t ol = o_base + o;
         VF_RC(RC.painted += (uint32_t)__popcll(bits); RC.paint_lines += bits ? 1u : 0u;)
         while (bits) {
@@ -1313,8 +1275,7 @@ next_item:
                             const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                            const int2 q0 = sXY[wave][v0], q1 = sXY[wave][v1], q2 = sXY[wave][v2];
-                            raster_fast(T, prim + 1u, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
+                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
                         }
                     }
                 }
