@@ -8,4 +8,4 @@ for path in sys.argv[1:]:
         agg[k] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     print(path)
     for (kern, c), v in sorted(agg.items()):
-        if "k_tile" in kern: print(f"  {kern:22s} {c:28s} {v/len(n[(kern,c)]):16.0f} per launch ({len(n[(kern,c)])} launches)")
+        if "k_tile" in kern or "k_block_setup" in kern or "k_resolve" in kern: print(f"  {kern:22s} {c:28s} {v/len(n[(kern,c)]):16.0f} per launch ({len(n[(kern,c)])} launches)")

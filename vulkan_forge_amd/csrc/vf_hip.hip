@@ -664,7 +664,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         // the items; then a handful of persistent workgroups of the complete variant take the items that met a clipped or
         // oversized primitive (normally none)
         uint32_t *redo_count = S.work_count + 3;
-        const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount), ntiles + kSplitBudget)),
+        const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount) * (1024u / (uint32_t)kTileThreads), ntiles + kSplitBudget)),
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
         const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \

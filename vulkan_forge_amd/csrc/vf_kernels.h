@@ -1055,18 +1055,20 @@ next_item:
     __syncthreads();
     VF_PH(14)                                              // row mask
 
-    // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands word 15 - w ----
+    // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands words 15 - w, 15 - w - kWaves, ... ----
     uint32_t nrows_total = 0;
     {
-        uint32_t above = 0;                                // hit rows in the words above this wave's word
-        for (uint32_t w = 0; w < 16u; ++w) {
-            const uint32_t c = (uint32_t)__popcll(s_rows[w]);
-            nrows_total += c;
-            if (w > 15u - wave) above += c;
+        uint32_t cnt[16];
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; ++w) { cnt[w] = (uint32_t)__popcll(s_rows[w]); nrows_total += cnt[w]; }
+        for (uint32_t word = 15u - wave; word < 16u; word -= (uint32_t)kWaves) {     // (unsigned wrap ends the loop)
+            uint32_t above = 0;                            // hit rows in the words above this one
+#pragma unroll
+            for (uint32_t w = 0; w < 16u; ++w) above += w > word ? cnt[w] : 0u;
+            const unsigned long long m = s_rows[word];
+            const uint32_t b = 63u - lane;                 // lane 0 takes the highest row of the word
+            if ((m >> b) & 1ull) s_allrows[above + (uint32_t)__popcll(b == 63u ? 0ull : m >> (b + 1u))] = (uint16_t)(word * 64u + b);
         }
-        const unsigned long long m = s_rows[15u - wave];
-        const uint32_t b = 63u - lane;                     // lane 0 takes the highest row of the word
-        if ((m >> b) & 1ull) s_allrows[above + (uint32_t)__popcll(b == 63u ? 0ull : m >> (b + 1u))] = (uint16_t)((15u - wave) * 64u + b);
     }
     __syncthreads();
 

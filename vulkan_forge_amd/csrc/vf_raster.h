@@ -105,9 +105,7 @@ VF_HD uint32_t rs_ubits(float f) { union { uint32_t u; float f; } c; c.f = f; re
 
 VF_HD void span_setup(const int32_t U[3], const int32_t V[3], bool swapped, int32_t u0c, int32_t v0c, int32_t n_outer, SpanSetup &S)
 {
-    bool ok = true;
-    uint32_t kinds = 0;                                    // bit 0: a lower edge seen, bit 1: an upper edge seen
-    int32_t zD0 = 0, zflags = 0;
+    uint32_t good = 0, flat = 0, kinds = 0;                // per-edge bits: error bound small enough | parallel to the lines; kinds seen
     const float span = (float)(n_outer + 1);
     const int32_t sw = swapped ? -1 : 0;                   // all ones when the orientation is mirrored
 #if VF_RASTER_DEVICE
@@ -118,35 +116,51 @@ VF_HD void span_setup(const int32_t U[3], const int32_t V[3], bool swapped, int3
         const int32_t dU = U[b] - U[a], dV = V[b] - V[a];
         // (Cu, Cv) = +-(dV, -dU), the sign is the mirroring's: the slope s = -Cu / Cv does not see it, the kind of the edge does.
         // r*(o) = (VR - v0c)/256 - tl/(256 Cv)  +  s * ((u0c - UR)/256 + o)            (alpha + beta r* = 0)
-        const bool flat = dU == 0;                                         // parallel to the lines: a per-line sign test instead
-        const float rc = flat ? 0.0f : rs_rcp((float)dU);                  // |dU| < 2^24: the conversion is exact
+        const float rc = rs_rcp((float)dU);                                // |dU| < 2^24: the conversion is exact (dU = 0: fixed up below)
         const float s = (float)dV * rc;                                    // = -Cu / Cv
         const float gg = (float)(u0c - U[a]) * (1.0f / 256.0f);
         const float cc = (float)(V[a] - v0c) * (1.0f / 256.0f);
         const float k = rs_fma(gg, s, cc);
-        // top-left rule in screen axes: A = dY > 0, or A = 0 and B = -dX > 0
-        const int32_t dY = swapped ? dU : dV, dX = swapped ? dV : dU;
-        const float tlf = (dY > 0 || (dY == 0 && dX < 0)) ? (1.0f / 256.0f) : 0.0f;
         // Error bound of t = fma(o, s, k) against r*: s carries 1.6 * 2^-23 relative (1-ulp reciprocal, one product) on |s| (|gg| + o);
         // the conversions of gg and cc, the fma that forms k, k - eps, the line's own fma and + 2 eps round at 2^-24 of values
         // bounded by |cc|, |k| <= |cc| + |gg||s| and the window (|t| < 2^7; outside the window nothing depends on the fraction):
         //     |t - r*| < ((|gg| + span) |s| * 2.1 + (2 |cc| + |gg||s|) + 2^7) * 2^-24  <  ((2 |gg| + span) |s| + |cc|) 2^-21 + 2^-16.
-        // The top-left rule's +1 moves the crossing by 1 / (256 |Cv|): FP32 cannot carry that next to cc, so the shift is part of
-        // the bound instead (a crossing that close to a pixel centre takes the exact route).
-        const float eps = rs_fma(rs_fma(rs_fma(fabsf(gg), 2.0f, span), fabsf(s), fabsf(cc)), 0x1.0p-21f, rs_fma(tlf, fabsf(rc), 0x1.0p-16f));
-        ok = ok && eps < 0.25f;                                            // (NaN / inf fail the comparison)
+        // The top-left rule's +1 (on top / left edges) moves the crossing by 1 / (256 |Cv|): FP32 cannot carry that next to cc, so
+        // the shift is part of every edge's bound instead (a crossing that close to a pixel centre takes the exact route).
+        const float eps = rs_fma(rs_fma(rs_fma(fabsf(gg), 2.0f, span), fabsf(s), fabsf(cc)), 0x1.0p-21f, rs_fma(fabsf(rc), 0x1.0p-8f, 0x1.0p-16f));
+        good |= (eps < 0.25f ? 1u : 0u) << i;                              // (NaN / inf fail the comparison)
+        flat |= (dU == 0 ? 1u : 0u) << i;
         // kind: Cv = -dU (mirrored: +dU) > 0 is a lower edge; upper edges are negated -- a sign-bit flip -- and get x = -1
-        const int32_t up = flat ? 0 : (((dU ^ sw) >> 31) ^ -1);           // all ones for an upper edge: Cv < 0 <=> (mirrored ? -dU : dU) > 0 ... see below
+        const int32_t up = ((dU ^ sw) >> 31) ^ -1;                         // all ones for an upper edge (dU != 0)
         const uint32_t sm = (uint32_t)up & 0x80000000u;
-        kinds |= flat ? 0u : (up ? 2u : 1u);
+        kinds |= (uint32_t)(up & 1) + 1u;                                  // bit 0: a lower edge seen, bit 1: an upper one
         S.s[i] = rs_bits(rs_ubits(s) ^ sm);
-        S.km[i] = flat ? -0x1.0p20f : rs_bits(rs_ubits(k) ^ sm) - eps;    // flat: a lower edge whose crossing lies far below the window
-        S.eps2[i] = flat ? 0.0f : eps + eps;
-        S.x[i] = up; S.c1[i] = up ? -kSpanBig : 1;
-        if (flat) { zD0 = u0c - U[a]; zflags = 1 | (((dV ^ sw) - sw) > 0 ? 2 : 0) | (tlf != 0.0f ? 4 : 0); }    // Cu = mirrored ? -dV : dV
+        S.km[i] = rs_bits(rs_ubits(k) ^ sm) - eps;
+        S.eps2[i] = eps + eps;
+        S.x[i] = up; S.c1[i] = (up & (-kSpanBig - 1)) + 1;
     }
-    S.zD0 = zD0; S.zflags = zflags;
-    S.regular = ok && kinds == 3u;
+    S.zD0 = 0; S.zflags = 0;
+    if (flat) {
+        // (rare) an edge parallel to the lines has no crossing: its slot becomes a lower edge far below the window, and a per-line sign
+        // test of D = (u0c - UR) + 256 o stands in for it (span_line).  At most one edge of a triangle with area can be flat.
+        kinds = 0;
+#if VF_RASTER_DEVICE
+#pragma unroll
+#endif
+        for (int i = 0; i < 3; ++i) {
+            const int a = i == 0 ? 1 : (i == 1 ? 2 : 0), b = i == 0 ? 2 : (i == 1 ? 0 : 1);
+            if ((flat >> i) & 1u) {
+                const int32_t dV = V[b] - V[a];
+                const int32_t Cu = swapped ? -dV : dV, dY = swapped ? 0 : dV, dX = swapped ? dV : 0;       // (dU = 0)
+                const bool tl = dY > 0 || (dY == 0 && dX < 0);                                              // top-left in screen axes
+                S.s[i] = 0.0f; S.km[i] = -0x1.0p20f; S.eps2[i] = 0.0f; S.x[i] = 0; S.c1[i] = 1;
+                S.zD0 = u0c - U[a]; S.zflags = 1 | (Cu > 0 ? 2 : 0) | (tl ? 4 : 0);
+            } else {
+                kinds |= S.x[i] ? 2u : 1u;
+            }
+        }
+    }
+    S.regular = ((good | flat) == 7u) && kinds == 3u;
 }
 
 // Stage 1: a span [lo, hi] that contains the true one (lo > hi: no pixel on this line).  F[] feeds span_confirm.
