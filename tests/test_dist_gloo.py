@@ -133,8 +133,9 @@ def test_tile_shards_double_buffered_exchange(world, W, H):
 
 def test_tile_layout_properties():
     from vulkan_forge_amd import dist as vdist
-    for W, H, n in ((4096, 4096, 8), (4096, 4096, 4), (1920, 1080, 8), (200, 150, 3), (64, 64, 2), (100, 100, 1), (130, 70, 6)):
-        skew = vdist.default_skew(n)
+    for W, H, n, skew in ((4096, 4096, 8, None), (4096, 4096, 4, None), (1920, 1080, 8, None), (200, 150, 3, None), (64, 64, 2, None), (100, 100, 1, None),
+                          (130, 70, 6, None), (4096, 4096, 8, 3), (1920, 1080, 8, 5), (200, 150, 3, 1)):
+        skew = vdist.default_skew(n) if skew is None else skew     # default: column stripes (0); skewed maps stay supported
         ntx, nty = (W + 63) // 64, (H + 63) // 64
         seen = np.full((nty, ntx), -1)
         sizes = []
@@ -149,5 +150,5 @@ def test_tile_layout_properties():
         assert vdist.stride_tiles(W, H, n, skew) == max(sizes)
         if ntx >= n:
             assert max(sizes) - min(sizes) <= nty                 # balanced to within one tile per tile row
-    assert vdist.default_skew(8) == 3 and vdist.default_skew(3) == 5 and vdist.default_skew(2) == 1
+    assert vdist.default_skew(8) == 0 and vdist.default_skew(3) == 0 and vdist.default_skew(2) == 0
     assert len(vdist.tile_layout(4096, 4096, 3, 8, 3)) == 512

@@ -9,9 +9,10 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 rank, n = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2, 8)
 W = H = G = 4096
-lut = np.load("tests/golden/colormaps_rgba8.npz")["viridis"]
+import vulkan_forge_amd as _vf; lut = _vf.colormap_rgba8("viridis")
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, lut); t.set_height(h); t.set_uniforms(b.camera_uniforms("default", W, H))
-if n > 1: t.set_tile_shard(rank, n, 3)
+skew = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+if n > 1: t.set_tile_shard(rank, n, skew)
 for _ in range(40): t.render()
 t.sync()

@@ -6,15 +6,16 @@ from vulkan_forge_amd import cabi
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 W = H = G = 4096
-lut = np.load("tests/golden/colormaps_rgba8.npz")["viridis"]
+SKEW = int(os.environ.get("VF_SKEW", "0"))
+import vulkan_forge_amd as _vf; lut = _vf.colormap_rgba8("viridis")
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, lut); t.set_height(h)
 for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
     for (r, n) in ((0, 1), (2, 8)):
         if n == 1: t.set_shard(0, 1, 64)
-        else: t.set_tile_shard(r, n, 3)
-        lay = cabi.tile_layout(W, H, r, n, 3, lib=t.lib) if n > 1 else None
+        else: t.set_tile_shard(r, n, SKEW)
+        lay = cabi.tile_layout(W, H, r, n, SKEW, lib=t.lib) if n > 1 else None
         for _ in range(24): t.render()
         t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
         ms = it[:, 2] * 1e-5

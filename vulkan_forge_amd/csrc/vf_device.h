@@ -59,6 +59,7 @@ struct FrameParams {
     uint32_t rank, nranks, band_shift, band_h;
     uint32_t local_rows;
     uint32_t shard_tiles;           // 0: whole frame / row bands (local rows, row-major); 1: interleaved tiles (tile-major)
+    uint32_t skew;                  // shard_tiles: tile (tx, ty) belongs to rank (tx + skew * ty) % nranks
     const uint32_t *tile_map;       // shard_tiles: local tile -> tx | ty << 16
     uint32_t clear_rgba;            // packed sRGB8 clear colour
     uint32_t shade_mode;            // 0 REFERENCE (terrain.wgsl as coded), 1 SPEC_T32 (the documented fragment stage)

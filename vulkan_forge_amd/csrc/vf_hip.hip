@@ -110,6 +110,7 @@ struct vf_terrain {
         VertexRec *vtx = nullptr;        // per block 81 x {X, Y, 1/w, h} (k_block_setup)
         BlockRec *recs = nullptr;        // per block: alive masks, exact pixel box
         ulonglong2 *gen = nullptr;       // per block: primitives that need the generic path (valid where the record says so)
+        uint32_t *seg_list = nullptr;    // 16-block segments with a block that reaches this shard's pixels (+ [nsegs] = their number)
         PixelBox *row_ranges = nullptr;  // per block row
         float4 *cap_seg = nullptr;       // per block: capsule axis (screen space)
         float *cap_rad = nullptr;        // per block: capsule radius
@@ -298,6 +299,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         A((void **)&S.vtx, (size_t)t->nblocks * kBlockStride * sizeof(VertexRec));
         A((void **)&S.recs, (size_t)t->nblocks * sizeof(BlockRec));
         A((void **)&S.gen, (size_t)t->nblocks * sizeof(ulonglong2));
+        A((void **)&S.seg_list, ((size_t)t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks) + 1) * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemset(S.seg_list, 0, ((size_t)t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks) + 1) * sizeof(uint32_t));
         A((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
         A((void **)&S.cap_seg, t->nblocks * sizeof(float4));
         A((void **)&S.cap_rad, t->nblocks * sizeof(float));
@@ -348,7 +351,7 @@ void vf_terrain_destroy(vf_terrain *t)
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_rgba_scratch, t->d_diag };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
-        void *sp[] = { S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
+        void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
         for (void *p : sp) if (p) (void)hipFree(p);
         if (S.planned) (void)hipEventDestroy(S.planned);
         if (S.drawn) (void)hipEventDestroy(S.drawn);
@@ -554,7 +557,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
-    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map;
+    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = t->skew;
     P.shade_mode = t->shade_mode; P.tex = t->d_height;
     const SrgbTables &T = tables();
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
@@ -628,13 +631,18 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // the split quantum comes from the same tile times the plan will read: summed by an extra workgroup of k_block_boxes, or --
     // when those times belong to the frame still being drawn -- by a kernel of its own after the wait below
     uint32_t *quantum = S.feedback + (size_t)t->ntx * t->nty;
+    const uint32_t nsegs_all = t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks);
+    uint32_t *seg_count = S.seg_list + nsegs_all;
     hipLaunchKernelGGL(k_block_boxes, dim3(t->nb + 1), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi,
-                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count);
+                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count, S.recs, S.seg_list, seg_count);
     // vertex stage + tile-independent culling, once per frame (streams ~1.3 KB per block into this frame's plan state): needs the
     // block boxes only, so it runs on a second stream beside k_plan / k_plan_sort -- all of them under the previous frame's tile kernel
     VF_HIP_TRY(hipEventRecord(S.boxed, side));
     VF_HIP_TRY(hipStreamWaitEvent(t->side2, S.boxed, 0));               // (orders it after S.drawn and the height cache too)
-    hipLaunchKernelGGL(k_block_setup, dim3(t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks)), dim3(kSetupThreads), 0, t->side2, P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen);
+    // (one short-lived workgroup per possible segment -- those beyond the list's length leave at once: workgroups that come and go
+    //  share the CUs with the previous frame's tile kernel more smoothly than a few long-lived ones)
+    hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, t->side2,
+                       P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen, S.seg_list, seg_count);
     VF_HIP_TRY(hipEventRecord(S.set_up, t->side2));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
@@ -659,7 +667,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
-        hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats);
+        hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats, seg_count);
         // one persistent workgroup per CU (a 1024-thread workgroup with 70 KB of LDS fills one), the fast variant, works through
         // the items; then a handful of persistent workgroups of the complete variant take the items that met a clipped or
         // oversized primitive (normally none)

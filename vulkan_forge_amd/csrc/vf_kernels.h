@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
                                                      float4 *__restrict__ cap_seg, float *__restrict__ cap_rad,
                                                      uint32_t *__restrict__ rc_lo, uint32_t *__restrict__ rc_hi,
                                                      const uint32_t *__restrict__ feedback, uint32_t ntiles_all, uint32_t *__restrict__ quantum,
-                                                     uint32_t *__restrict__ work_count)
+                                                     uint32_t *__restrict__ work_count, BlockRec *__restrict__ recs,
+                                                     uint32_t *__restrict__ seg_list, uint32_t *__restrict__ seg_count)
 {
     if (blockIdx.x == P.nb) {                               // (uniform per workgroup)
         // this frame's queue words start at zero: [0] work items, [1] split budget used, [2] queue head, [3] items for the complete
@@ -122,9 +123,11 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
     }
     __shared__ int s_rr[4];   // x0, y0 (min) / x1, y1 (max)
     __shared__ uint32_t s_lo[kMaxTileCols], s_hi[kMaxTileCols];   // this block row's [first, last+1) block per tile column
+    __shared__ uint32_t s_seg[(1024 + 15) / 16];                  // per 16-block segment of the row: does any block reach this shard's pixels?
     const uint32_t by = blockIdx.x;
     if (threadIdx.x == 0) { s_rr[0] = 0x7FFF; s_rr[1] = 0x7FFF; s_rr[2] = -1; s_rr[3] = -1; }
     for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += blockDim.x) { s_lo[tc] = 0xFFFFFFFFu; s_hi[tc] = 0u; }
+    for (uint32_t k = threadIdx.x; k < (1024u + 15u) / 16u; k += blockDim.x) s_seg[k] = 0u;
     __syncthreads();
     for (uint32_t bx = threadIdx.x; bx < P.nb; bx += blockDim.x) {
         const uint32_t b = by * P.nb + bx;
@@ -174,7 +177,31 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
         } else {
             r.x0 = 0; r.y0 = 0; r.x1 = W1; r.y1 = H1;         // no bound available: the whole target
         }
+        // A shard draws only its own tiles (or row bands): a block whose box meets none of them is dropped here, before the set-up
+        // pass, the block ranges and the tile kernel ever see it -- geometry work is sharded with the pixels.
+        if (P.nranks > 1u && r.x0 <= r.x1) {
+            bool mine = false;
+            if (P.shard_tiles) {
+                const uint32_t tx0 = (uint32_t)r.x0 / kTileW, tx1 = (uint32_t)r.x1 / kTileW, ty0 = (uint32_t)r.y0 / kTileH, ty1 = (uint32_t)r.y1 / kTileH;
+                if (tx1 - tx0 + 1u >= P.nranks) mine = true;             // a full period of tile columns: every rank owns one in each row
+                for (uint32_t ty = ty0; ty <= ty1 && !mine; ++ty) {
+                    // owner(tx, ty) = (tx + skew ty) % nranks: the first column >= tx0 this rank owns in row ty
+                    const uint32_t want = (P.rank + P.nranks - (P.skew * ty) % P.nranks) % P.nranks;
+                    const uint32_t first = tx0 + (want + P.nranks - tx0 % P.nranks) % P.nranks;
+                    mine = first <= tx1;
+                }
+            } else {
+                for (uint32_t bd = (uint32_t)r.y0 >> P.band_shift; bd <= ((uint32_t)r.y1 >> P.band_shift) && !mine; ++bd) mine = bd % P.nranks == P.rank;
+            }
+            if (!mine) { r.x0 = 1; r.y0 = 1; r.x1 = 0; r.y1 = 0; }
+        }
         boxes[b] = r;
+        if (r.x0 <= r.x1) s_seg[bx / 16u] = 1u;            // the set-up pass works through the segments that hold such a block ...
+        else {                                             // ... and never sees the others: their records say "nothing to draw" from here
+            BlockRec e;
+            e.box = PixelBox{ 1, 1, 0, 0 }; e.flags = 0u; e.count = 0u; e.alive_even = 0ull; e.alive_odd = 0ull;
+            recs[b] = e;
+        }
         float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
         float rad = INFINITY;                                   // no capsule bound unless all 8 corners are regular
         if (regular == 8) {
@@ -205,6 +232,8 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
     }
     __syncthreads();
     for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += blockDim.x) { rc_lo[tc * P.nb + by] = s_lo[tc]; rc_hi[tc * P.nb + by] = s_hi[tc]; }   // [tile column][block row]: a tile reads its column's rows contiguously
+    for (uint32_t k = threadIdx.x; k < (P.nb + 15u) / 16u; k += blockDim.x)
+        if (s_seg[k]) seg_list[atomicAdd(seg_count, 1u)] = by | (k << 16);      // (order is irrelevant; the counter is zeroed by the frame's k_clear)
     if (threadIdx.x == 0) {
         PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
@@ -249,30 +278,25 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
 
 __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
                                                                const PixelBox *__restrict__ cons_boxes, VertexRec *__restrict__ vtx,
-                                                               BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen)
+                                                               BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen,
+                                                               const uint32_t *__restrict__ seg_list, const uint32_t *__restrict__ seg_count)
 {
     __shared__ int2 sXY[kBlockVerts][kSegStride];
     __shared__ float2 sWH[kBlockVerts][kSegStride];
     __shared__ uint8_t sF[kBlockVerts][kSegStride];
-    __shared__ uint32_t s_on_target, s_flagged;
+    __shared__ uint32_t s_flagged;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t segs = (P.nb + kSegBlocks - 1) / kSegBlocks;
-    const uint32_t by = blockIdx.x / segs, bx0 = (blockIdx.x - by * segs) * kSegBlocks;
+    // the segments k_block_boxes listed: those with a block that can reach this shard's part of the target
+    const uint32_t nseg = *seg_count;
+    for (uint32_t item = blockIdx.x; item < nseg; item += gridDim.x) {
+    const uint32_t code = seg_list[item];
+    const uint32_t by = code & 0xFFFFu, bx0 = (code >> 16) * kSegBlocks;
     const uint32_t nblk = min((uint32_t)kSegBlocks, P.nb - bx0);
     const uint32_t b0 = by * P.nb + bx0;
-    if (tid == 0) { s_on_target = 0u; s_flagged = 0u; }
+    __syncthreads();                                       // the previous segment's LDS reads are done
+    if (tid == 0) s_flagged = 0u;
     __syncthreads();
-    if (tid < nblk) { const PixelBox cb = cons_boxes[b0 + tid]; if (cb.x0 <= cb.x1) s_on_target = 1u; }
-    __syncthreads();
-    if (!s_on_target) {                                    // (uniform) the whole segment is clipped away or off the target
-        if (tid < nblk) {
-            BlockRec rec;
-            rec.box = PixelBox{ 1, 1, 0, 0 }; rec.flags = 0u; rec.count = 0u; rec.alive_even = 0ull; rec.alive_odd = 0ull;
-            recs[b0 + tid] = rec;
-        }
-        return;
-    }
     // ---- 1. vertex stage: 9 rows x (8 nblk + 1) columns, every vertex once ----
     const uint32_t i0 = bx0 * kBlockCells, j0 = by * kBlockCells, ncols = nblk * kBlockCells + 1u;
     bool flagged = false;
@@ -366,6 +390,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, co
             recs[b] = rec;
             if (g0 | g1) gen[b] = make_ulonglong2(g0, g1);
         }
+    }
     }
 }
 
@@ -886,8 +911,12 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
 // Background tiles: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
 // (this pass is pure HBM write bandwidth: 49 MiB of the C4 default frame); edge tiles and odd widths go pixel by pixel.
 __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__restrict__ background, uint32_t *__restrict__ rgba,
-                                               uint32_t *__restrict__ vis_out, uint32_t *__restrict__ stats, uint32_t nstats)
+                                               uint32_t *__restrict__ vis_out, uint32_t *__restrict__ stats, uint32_t nstats,
+                                               uint32_t *__restrict__ seg_count)
 {
+    // the frame's set-up pass has read its segment list (this launch waits for it): empty it for the frame after next, whose
+    // k_block_boxes fills it again after this frame is drawn
+    if (blockIdx.x == 0 && threadIdx.x == 0) *seg_count = 0u;
     // diagnostics (timing enabled): this frame's per-item statistics start at zero -- spread over the launch, no memset dispatch
     if (stats) for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < nstats; k += gridDim.x * 256u) stats[k] = 0u;
     if ((background[blockIdx.x] & 1u) == 0u) return;
