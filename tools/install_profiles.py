@@ -1,46 +1,121 @@
 #!/usr/bin/env python3
-"""Copy one profile pass from gpurun_out/ into profiles/ under a tag, replacing the previous tag's files, and refresh
-profiles/pmc_traffic.json (FETCH/WRITE passes via tools/pmc_summary.py, SQ passes via tools/pmc_sq_summary.py).
+"""Copy one tools/profile_round.sh session from gpurun_out/<tag>/ into profiles/<prefix>_* and rebuild profiles/pmc_traffic.json.
 
-usage: install_profiles.py NEW_TAG OLD_TAG PMC_PREFIX      e.g.  install_profiles.py r01_q r01_p pmc22
-expects gpurun_out/: bench_<NEW_TAG-with-last-_-kept>.log, prof_<tag>/run_kernel_stats.csv, <PMC_PREFIX>_{default,fill}_{FETCH,WRITE}_SIZE/,
-<PMC_PREFIX>_sq_{a,b}/, shards_<tag>.log, toptiles_<tag>.log, schedule_<tag>.log, phases_<tag>.log, pytest_gpu.log  (tag = NEW_TAG without '_')."""
-import json, os, re, shutil, subprocess, sys
-new, old, pmc = sys.argv[1:4]
+usage: install_profiles.py <tag under gpurun_out> <prefix in profiles/>      e.g.  install_profiles.py r02_m r02
+
+profiles/pmc_traffic.json is what bench.py reads for roofline.traffic and the SQ utilisation figures.  Every entry carries the
+sha256 of the libvf_hip.so the counters were collected on (lib_sha256): bench.py reports them only when that is the library it
+loaded, and says "traffic_stale" otherwise.
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB.  WRITE_SIZE is exact for our stores.
+FETCH_SIZE reports 1/2 of the bytes of wide coalesced streams on gfx950, so it is doubled (the guide's correction); our reads are
+4 to 16 B per lane, which makes the doubled figure an upper bound -- both values are recorded.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag, prefix = sys.argv[1:3]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
-short = new.replace("_", "", 1) if new.count("_") == 2 else new            # r01_q -> r01q
-short = new[:3] + new[4:] if new[3] == "_" else new
-names = ["bench.json", "kernel_stats.csv", "pmc_FETCH_SIZE_default.csv", "pmc_WRITE_SIZE_default.csv", "emulated_shards.log", "top_items.log",
-         "schedule.log", "phase_cycles.log", "pytest_gpu.log", "sq_counters.txt"]
-for n in names:
-    f = os.path.join(P, f"{old}_{n}")
-    if os.path.exists(f): os.remove(f)
-open(os.path.join(P, f"{new}_bench.json"), "w").write(open(os.path.join(G, f"bench_{new}.log")).read().strip().splitlines()[-1] + "\n")
-shutil.copy(os.path.join(G, f"prof_{short}", "run_kernel_stats.csv"), os.path.join(P, f"{new}_kernel_stats.csv"))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    shutil.copy(os.path.join(G, f"{pmc}_default_{c}", "run_counter_collection.csv"), os.path.join(P, f"{new}_pmc_{c}_default.csv"))
-for src, dst in (("shards", "emulated_shards"), ("toptiles", "top_items"), ("schedule", "schedule"), ("phases", "phase_cycles")):
-    shutil.copy(os.path.join(G, f"{src}_{short}.log"), os.path.join(P, f"{new}_{dst}.log"))
-open(os.path.join(P, f"{new}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
-for cam in ("default", "fill"):
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), f"4096x4096_g4096_{cam}_n1",
-                           os.path.join(G, f"{pmc}_{cam}_FETCH_SIZE", "run_counter_collection.csv"),
-                           os.path.join(G, f"{pmc}_{cam}_WRITE_SIZE", "run_counter_collection.csv"), short], stdout=subprocess.DEVNULL)
-sq = subprocess.check_output([sys.executable, os.path.join(root, "tools", "pmc_sq_summary.py"),
-                              os.path.join(G, f"{pmc}_sq_a", "run_counter_collection.csv"), os.path.join(G, f"{pmc}_sq_b", "run_counter_collection.csv")]).decode()
-open(os.path.join(P, f"{new}_sq_counters.txt"), "w").write(sq)
-v = {m.group(1): int(m.group(2)) for m in re.finditer(r"vf::k_tile<false, false>\s+(\S+)\s+(\d+)", sq)}
+G, P = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+lib_hash = open(os.path.join(G, "lib_sha256.txt")).read().strip()
+
+
+def last_json_line(path):
+    return [l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1]
+
+
+def per_kernel(path, agg_last=None):
+    """{(kernel, counter): average per launch} over all launches (or the last `agg_last`)."""
+    vals = collections.defaultdict(lambda: collections.OrderedDict())
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])
+        d = int(r["Dispatch_Id"])
+        vals[k][d] = vals[k].get(d, 0.0) + float(r["Counter_Value"])
+    out = {}
+    for k, v in vals.items():
+        xs = list(v.values())
+        xs = xs[-agg_last:] if agg_last else xs
+        out[k] = sum(xs) / len(xs)
+    return out
+
+
+def copy(src, dst):
+    shutil.copy(os.path.join(G, src), os.path.join(P, f"{prefix}_{dst}"))
+
+
+open(os.path.join(P, f"{prefix}_bench.json"), "w").write(last_json_line(os.path.join(G, "bench.json")) + "\n")
+open(os.path.join(P, f"{prefix}_bench_c5.json"), "w").write(last_json_line(os.path.join(G, "bench_c5.json")) + "\n")
+open(os.path.join(P, f"{prefix}_rehearse_4ranks.json"), "w").write(last_json_line(os.path.join(G, "rehearse_4ranks.json")) + "\n")
+copy("kernel_stats.csv", "kernel_stats.csv")
+for n in ("fetch_default", "write_default", "frag_fetch", "frag_write"):
+    copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
+for n in ("ranks.log", "rank_timeline.log", "top_items.log"):
+    copy(n, n)
+open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
+
+# ---- SQ utilisation (default camera) ------------------------------------------------------------------------------------
+sq = {}
+lines = []
+for n in ("sq_a", "sq_b"):
+    pk = per_kernel(os.path.join(G, f"pmc_{n}.csv"))
+    lines.append(f"pmc_{n}.csv (averages per launch)")
+    for (kern, ctr), v in sorted(pk.items()):
+        if "k_tile" in kern or "k_block_setup" in kern:
+            lines.append(f"  {kern:26s} {ctr:26s} {v:16.0f}")
+        if kern == "vf::k_tile<false, false>":
+            sq[ctr] = v
+open(os.path.join(P, f"{prefix}_sq_counters.txt"), "w").write("\n".join(lines) + "\n")
+
 path = os.path.join(P, "pmc_traffic.json")
-d = json.load(open(path))
-k = "4096x4096_g4096_default_n1"
-d[k]["sq"] = {"valu_busy_frac": v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * v["GRBM_GUI_ACTIVE"] / 8), "valu_wave_insts": float(v["SQ_INSTS_VALU"]),
-              "salu_wave_insts": float(v["SQ_INSTS_SALU"]), "lds_wave_insts": float(v["SQ_INSTS_LDS"]),
-              "active_lanes_per_valu_inst": v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"],
-              "note": f"k_tile fast variant; busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs); passes {new}_sq_counters.txt"}
-json.dump(d, open(path, "w"), indent=1)
-b = json.load(open(os.path.join(P, f"{new}_bench.json")))
-print("bench:", round(b["value"]), "Mpix/s", round(b["ms_per_step"], 4), "ms; kernel", round(b["roofline"]["kernel_ms"], 4), "ms; roofline", round(b["roofline"]["achieved"], 1),
-      "GB/s", round(100 * b["roofline"]["frac"], 2), "%; other:", b.get("other_camera"), "check:", b.get("gathered_frame_equals_single_rank_frame"), "cpu:", round(b["cpu_baseline"]["value"], 2))
-print("sq:", {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in d[k]["sq"].items() if kk != "note"})
-print("k_tile KiB:", d[k]["k_tile"], "traffic", d[k]["hbm_bytes_per_launch"])
+data = json.load(open(path)) if os.path.exists(path) else {}
+frame = ["vf::k_block_boxes", "vf::k_block_setup", "vf::k_plan", "vf::k_plan_sort", "vf::k_clear", "vf::k_tile"]
+for cam in ("default", "fill"):
+    f = per_kernel(os.path.join(G, f"pmc_fetch_{cam}.csv"), agg_last=3)
+    w = per_kernel(os.path.join(G, f"pmc_write_{cam}.csv"), agg_last=3)
+
+    def fold(d, ctr):
+        """the tile kernel runs as two launches (fast variant, then the complete variant for items it handed over): one entry"""
+        out = collections.defaultdict(float)
+        for (k, c), v in d.items():
+            if c == ctr:
+                out["vf::k_tile" if k.startswith("vf::k_tile<false") else k] += v
+        return out
+    f, w = fold(f, "FETCH_SIZE"), fold(w, "WRITE_SIZE")
+    tile_f, tile_w = f.get("vf::k_tile", 0.0), w.get("vf::k_tile", 0.0)
+    entry = {
+        "tag": prefix, "lib_sha256": lib_hash,
+        "k_tile": {"FETCH_SIZE_KiB": tile_f, "WRITE_SIZE_KiB": tile_w},
+        "frame_kernels": {k: {"FETCH_SIZE_KiB": f.get(k, 0.0), "WRITE_SIZE_KiB": w.get(k, 0.0)} for k in frame},
+        "hbm_bytes_per_launch": int((2 * tile_f + tile_w) * 1024),            # k_tile, FETCH doubled (guide's gfx950 correction)
+        "hbm_bytes_per_launch_fetch_uncorrected": int((tile_f + tile_w) * 1024),
+        "hbm_bytes_per_frame_all_kernels": int((2 * sum(f.get(k, 0.0) for k in frame) + sum(w.get(k, 0.0) for k in frame)) * 1024),
+    }
+    if cam == "default" and sq:
+        entry["sq"] = {
+            "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
+            "valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq["SQ_INSTS_SALU"], "lds_wave_insts": sq["SQ_INSTS_LDS"],
+            "active_lanes_per_valu_inst": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+            "wave_cycles_active_wait_stall": [sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                                              sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]],
+            "note": f"k_tile fast variant; busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs) -- the counter ticks in quad-cycles, "
+                    f"one per instruction at least, so this is an upper bound of the issue utilisation; passes {prefix}_sq_counters.txt",
+        }
+    data[f"4096x4096_g4096_{cam}_n1"] = entry
+
+# ---- the fragment stage on its own (k_resolve): measured traffic next to the algorithmic bytes ----------------------------
+ff = per_kernel(os.path.join(G, "pmc_frag_fetch.csv"))
+fw = per_kernel(os.path.join(G, "pmc_frag_write.csv"))
+frag = {k[0]: v for k, v in ff.items() if "k_resolve" in k[0]}
+fragw = {k[0]: v for k, v in fw.items() if "k_resolve" in k[0]}
+data["fragment_stage_k_resolve"] = {"tag": prefix, "lib_sha256": lib_hash, "FETCH_SIZE_KiB_avg_over_both_cameras": frag, "WRITE_SIZE_KiB_avg_over_both_cameras": fragw,
+                                    "note": "tools/exp_fragment.py: default camera first, then fill; per-dispatch values in profiles/%s_pmc_frag_*.csv" % prefix}
+json.dump(data, open(path, "w"), indent=1)
+b = json.loads(open(os.path.join(P, f"{prefix}_bench.json")).read())
+print("bench:", round(b["value"]), "Mpix/s", round(b["ms_per_step"], 4), "ms; kernel", round(b["roofline"]["kernel_ms"], 4), "ms; hbm frac", round(100 * b["roofline"]["frac"], 2),
+      "%; other:", b.get("other_camera"), "check:", b.get("gathered_frame_equals_single_rank_frame"))
+print("sq:", data["4096x4096_g4096_default_n1"].get("sq"))
+print("traffic default:", data["4096x4096_g4096_default_n1"]["hbm_bytes_per_launch"], "fill:", data["4096x4096_g4096_fill_n1"]["hbm_bytes_per_launch"])
