@@ -10,6 +10,7 @@ import vulkan_forge_amd as _vf; lut = _vf.colormap_rgba8("viridis")
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 names = ["setup", "pull/cull", "vertex", "classify", "span raster", "completion/rescan", "chunk-end wait", "fragment"]
 t = cabi.Terrain(W, H, G, lut, lib=cabi.load(sys.argv[1])); t.set_height(h)
+if len(sys.argv) > 3: t.set_tile_shard(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)      # one rank of N
 for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
     for _ in range(24): t.render()

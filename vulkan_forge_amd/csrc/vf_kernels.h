@@ -768,6 +768,35 @@ __device__ __forceinline__ uint32_t rescan_open_rows(uint32_t *vis, uint32_t *co
     return nfinal;
 }
 
+// The same for a narrow column strip (a heavy tile cut into 4, 8 or 16 strips is 16, 8 or 4 pixels wide): lane = ROW, one trip per four
+// columns instead of one per four open rows -- a 4-pixel strip is rescanned with one trip of LDS reads instead of up to sixteen, and on
+// a multi-GPU rank most heavy items are such strips (completion + rescans were a fifth of a rank's wave time).  Column masks by
+// ballot, row masks per lane.  Final stays final (the first id only falls), so the masks are simply rebuilt.
+__device__ __forceinline__ uint32_t rescan_strip(uint32_t *vis, uint32_t *colfin, uint32_t *rowfin, uint32_t lane, uint32_t first_id,
+                                                 int32_t width, int32_t height)
+{
+    const bool row_ok = (int32_t)lane < height;
+    uint32_t rowbits = 0;                                  // (width <= 16: the row mask fits the low word)
+    for (int32_t c0 = 0; c0 < width; c0 += 4) {            // uniform
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (row_ok && c0 + k < width) ? vis[vis_index(c0 + k, (int32_t)lane)] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c0 + k >= width) break;                    // uniform
+            const bool fin = row_ok && v[k] >= first_id;
+            const unsigned long long cm = __ballot(fin);
+            if (lane == 0) { colfin[2 * (c0 + k)] = (uint32_t)cm; colfin[2 * (c0 + k) + 1] = (uint32_t)(cm >> 32); }
+            rowbits |= (fin ? 1u : 0u) << (c0 + k);
+        }
+    }
+    if (row_ok) { rowfin[2 * lane] = rowbits; rowfin[2 * lane + 1] = 0u; }
+    uint32_t nfinal = (uint32_t)__popc(rowbits);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nfinal += __shfl_xor(nfinal, o);
+    return nfinal;
+}
+
 __device__ __forceinline__ uint32_t rescan_final(uint32_t *vis, uint32_t *colfin, uint32_t *rowfin, uint32_t lane, uint32_t first_id,
                                                  int32_t row_begin, int32_t row_end)
 {
@@ -1328,7 +1357,9 @@ next_item:
             const uint32_t pub = *v_published;
             if (fr > pub && (fr - pub >= (uint32_t)kRescanEvery || fr == nsteps)) {
                 // steps 0 .. fr-1 are complete: everything owned by ids >= first id of step fr-1 is final
-                const uint32_t nfinal = rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, T.py_hi - T.py_lo + 1);
+                const int32_t sw = T.px_hi - T.px_lo + 1, sh = T.py_hi - T.py_lo + 1;
+                const uint32_t nfinal = sw <= 16 ? rescan_strip(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], sw, sh)
+                                                 : rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, sh);
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) s_done = 1u; }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
