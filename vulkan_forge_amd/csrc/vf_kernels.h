@@ -1133,7 +1133,7 @@ next_item:
     VF_PH(8)                                                // item start, tile state, row list
     const uint32_t hit_words = (P.nb + 63u) / 64u;
     volatile uint32_t *v_pending = s_pending;
-    volatile uint32_t *v_done = &s_done, *v_frontier = &s_frontier, *v_published = &s_published;
+    volatile uint32_t *v_frontier = &s_frontier, *v_published = &s_published;
 
     for (uint32_t cursor = 0; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
         // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
@@ -1238,7 +1238,8 @@ next_item:
         // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
         uint32_t my_blocks = 0;
         for (;;) {
-            if (*v_done) break;
+            // (a finished tile pushes the list counter past the list's end: one LDS round trip tells "nothing left" and "tile final" apart
+            //  from "here is your block" -- a separate look at a done flag was one more dependent round trip per block: -1.6 %)
             uint32_t idx = 0;
             if (lane == 0) idx = atomicAdd(&s_next, 1u);
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
@@ -1360,7 +1361,7 @@ next_item:
                 const int32_t sw = T.px_hi - T.px_lo + 1, sh = T.py_hi - T.py_lo + 1;
                 const uint32_t nfinal = sw <= 16 ? rescan_strip(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], sw, sh)
                                                  : rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, sh);
-                if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) s_done = 1u; }
+                if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) { s_done = 1u; atomicOr(&s_next, 0x40000000u); } }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
             VF_PH(5)
