@@ -276,15 +276,29 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// wave-wide minimum / maximum of packed (x, y) int16 pairs by DPP (no LDS round trips): quad, half row, row, then across the rows;
+// the result is valid in lane 63
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce_pk_i16(uint32_t v)
+{
+    auto op = [](uint32_t a, uint32_t b) { return MAX ? pk_max_i16(a, b) : pk_min_i16(a, b); };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));    // row_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));    // row_bcast:15 into rows 1 and 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
                                                                const PixelBox *__restrict__ cons_boxes, VertexRec *__restrict__ vtx,
                                                                BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen,
                                                                const uint32_t *__restrict__ seg_list, const uint32_t *__restrict__ seg_count)
 {
     __shared__ int2 sXY[kBlockVerts][kSegStride];
-    __shared__ float2 sWH[kBlockVerts][kSegStride];
     __shared__ uint8_t sF[kBlockVerts][kSegStride];
-    __shared__ uint32_t s_flagged;
+    __shared__ uint32_t s_flagged, s_need;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     // the segments k_block_boxes listed: those with a block that can reach this shard's part of the target
@@ -295,51 +309,49 @@ __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, co
     const uint32_t nblk = min((uint32_t)kSegBlocks, P.nb - bx0);
     const uint32_t b0 = by * P.nb + bx0;
     __syncthreads();                                       // the previous segment's LDS reads are done
-    if (tid == 0) s_flagged = 0u;
+    if (wave == 0) {                                       // which blocks of the segment have anything to draw (k_block_boxes' conservative box)?
+        bool need = false;
+        if (lane < nblk) { const PixelBox cb = cons_boxes[b0 + lane]; need = cb.x0 <= cb.x1; }
+        const unsigned long long m = __ballot(need);
+        if (lane == 0) { s_need = (uint32_t)m; s_flagged = 0u; }
+    }
     __syncthreads();
-    // ---- 1. vertex stage: 9 rows x (8 nblk + 1) columns, every vertex once ----
+    const uint32_t need = s_need;
+    // ---- 1. vertex stage: 9 rows x (8 nblk + 1) columns, every vertex once; its record {X, Y, 1/w, h} goes straight to the block(s)
+    //         it belongs to (an edge column to two), 16 bytes per lane -- the tile kernel's raster and fragment stages read these ----
     const uint32_t i0 = bx0 * kBlockCells, j0 = by * kBlockCells, ncols = nblk * kBlockCells + 1u;
     bool flagged = false;
     for (uint32_t v = tid; v < (uint32_t)(kBlockVerts * kSegCols); v += kSetupThreads) {
         const uint32_t r = v / (uint32_t)kSegCols, c = v - r * (uint32_t)kSegCols;
         if (c >= ncols) continue;
         const uint32_t i = i0 + c, j = j0 + r;
-        int32_t X = 0, Y = 0;
-        float rw = 0.0f, h = 0.0f;
+        const uint32_t k = min(c >> 3, nblk - 1u), li = c - 8u * k;    // the cache is per block too: column 8 k' is also column 8 of block k' - 1
+        VertexRec o;
+        o.X = 0; o.Y = 0; o.rw = 0.0f; o.h = 0.0f;
         uint32_t fl = F_BAD;
         if (i < P.n && j < P.n) {
-            const uint32_t k = min(c >> 3, nblk - 1u);    // the cache is per block: column 8 k' is also column 8 of block k' - 1
-            h = hblk[(size_t)(b0 + k) * kBlockStride + r * kBlockVerts + (c - 8u * k)];
-            const ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), h);
+            o.h = hblk[(size_t)(b0 + k) * kBlockStride + r * kBlockVerts + li];
+            const ClipVert cv = vertex_shader(P, grid_coord(P, i), grid_coord(P, j), o.h);
             fl = vertex_flags(cv);
-            if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, X, Y, rw)) fl |= F_NOSNAP;
+            if (!(fl & F_BAD) && !snap_vertex(cv.x, cv.y, cv.w, P.hw, P.hh, o.X, o.Y, o.rw)) fl |= F_NOSNAP;
+            flagged |= fl != 0u;
         }
-        flagged |= fl != 0u && i < P.n && j < P.n;
-        sXY[r][c] = make_int2(X, Y); sWH[r][c] = make_float2(rw, h); sF[r][c] = (uint8_t)fl;
+        sXY[r][c] = make_int2(o.X, o.Y); sF[r][c] = (uint8_t)fl;
+        if ((need >> k) & 1u) vtx[(size_t)(b0 + k) * kBlockStride + r * kBlockVerts + li] = o;
+        if (li == 0u && k > 0u && ((need >> (k - 1u)) & 1u)) vtx[(size_t)(b0 + k - 1u) * kBlockStride + r * kBlockVerts + 8u] = o;
     }
     if (__any(flagged) && lane == 0) s_flagged = 1u;
     __syncthreads();
     const bool any_flag = s_flagged != 0u;                 // (uniform) false for every ordinary view: the flag tests drop out
-    // ---- 2./3. one wave per block ----
+    // ---- 2. one wave per block, lane = cell ----
     for (uint32_t k = wave; k < nblk; k += kSetupThreads / 64) {
         const uint32_t b = b0 + k, cbase = k * kBlockCells;
-        const PixelBox cb = cons_boxes[b];                 // conservative box of the block's height bounds (k_block_boxes)
         BlockRec rec;
         rec.box = PixelBox{ 1, 1, 0, 0 }; rec.flags = 0u; rec.count = 0u; rec.alive_even = 0ull; rec.alive_odd = 0ull;
-        if (cb.x0 > cb.x1) {                               // (uniform) clipped away or off the target: nothing to draw
+        if (!((need >> k) & 1u)) {                         // (uniform) clipped away or off the target: nothing to draw
             if (lane == 0) recs[b] = rec;
             continue;
         }
-        // the block's 81 vertex records, 16 bytes per lane
-        for (uint32_t v = lane; v < (uint32_t)(kBlockVerts * kBlockVerts); v += 64u) {
-            const uint32_t r = v / (uint32_t)kBlockVerts, li = v - r * (uint32_t)kBlockVerts;
-            const int2 xy = sXY[r][cbase + li];
-            const float2 wh = sWH[r][cbase + li];
-            VertexRec o;
-            o.X = xy.x; o.Y = xy.y; o.rw = wh.x; o.h = wh.y;
-            vtx[(size_t)b * kBlockStride + v] = o;
-        }
-        // lane = cell
         const uint32_t lj = lane >> 3, li = lane & 7u;
         int c0 = 0, c1 = 0;                                // 0 dead, 1 alive, 2 generic
         uint32_t lo = 0x7FFF7FFFu, hi = 0x80008000u;       // packed (x, y) int16: running min of (px0, py0), max of (px1, py1)
@@ -377,16 +389,13 @@ __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, co
             c1 = classify(fb, fc, fd, pb, pc, pd);        // (b, c, d)
         }
         const unsigned long long a0 = __ballot(c0 == 1), a1 = __ballot(c1 == 1), g0 = __ballot(c0 == 2), g1 = __ballot(c1 == 2);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = pk_min_i16(lo, (uint32_t)__shfl_xor((int)lo, o));
-            hi = pk_max_i16(hi, (uint32_t)__shfl_xor((int)hi, o));
-        }
+        lo = wave_reduce_pk_i16<false>(lo);                // (valid in lane 63, which writes the record)
+        hi = wave_reduce_pk_i16<true>(hi);
         rec.alive_even = a0; rec.alive_odd = a1;
         rec.count = (uint32_t)(__popcll(a0) + __popcll(a1));
-        if (g0 | g1) { rec.flags = kRecGeneric; rec.box = cb; }      // generic primitives: only the conservative bound holds
+        if (g0 | g1) { rec.flags = kRecGeneric; rec.box = cons_boxes[b]; }   // generic primitives: only the conservative bound holds
         else if (rec.count) rec.box = PixelBox{ (int16_t)(lo & 0xFFFFu), (int16_t)(lo >> 16), (int16_t)(hi & 0xFFFFu), (int16_t)(hi >> 16) };
-        if (lane == 0) {
+        if (lane == 63u) {
             recs[b] = rec;
             if (g0 | g1) gen[b] = make_ulonglong2(g0, g1);
         }
