@@ -154,6 +154,9 @@ int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines,
 /* debug/parity: per-pixel visible primitive id + 1 (0 = background) of the last render, local rows */
 int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 
+/* enable: 0 off; 1 device times (HIP events around the frame's kernels) and the per-item statistics behind
+ * vf_terrain_debug_item_stats / vf_timings.blocks_* (the tile kernel then writes them: a few atomics per drawn block);
+ * 2 device times only -- the kernels run exactly as they do untimed (what bench.py times; blocks_* read 0). */
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 /* diagnostics (timing enabled): per work item of the last frame (a busy tile, or one column strip of a heavy tile), in

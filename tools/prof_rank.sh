@@ -9,9 +9,9 @@ python3 - "$out/prof/run_kernel_trace.csv" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last 6 frames: print the timeline relative to the k_clear of each frame
+# last 6 frames: print the timeline relative to the start of a frame's main tile kernel
 names = [(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vf::", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-clears = [i for i, n in enumerate(names) if n[0] == "k_clear"]
+clears = [i for i, n in enumerate(names) if n[0] == "k_tile<false, false>"]
 if len(clears) > 8:
     t0 = names[clears[-6]][1]
     for n, s, e in names[clears[-6]:clears[-3]]:

@@ -140,6 +140,7 @@ struct vf_terrain {
     // timing: a ring of (start, after block boxes, after plan, after tile) events, one set per rendered frame
     static constexpr int kTimingRing = 64;
     bool timing = false;
+    bool stats_on = false;               // per-item statistics as well (vf_terrain_enable_timing(t, 1)); 2 = device times only
     hipEvent_t ev[kTimingRing][5] = {};   // plan start, after block boxes, after plan (side stream); after tile, before clear (caller's stream)
     hipEvent_t entry = nullptr;          // caller's stream at render entry (orders a height-cache rebuild after the caller's work)
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
@@ -658,7 +659,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
-    uint32_t *stats = t->timing ? t->d_stats : nullptr;
+    uint32_t *stats = t->timing && t->stats_on ? t->d_stats : nullptr;
     const uint32_t nstats = (uint32_t)(4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32);   // zeroed by k_clear (no memset dispatch)
     VF_HIP_TRY(hipStreamWaitEvent(s, S.planned, 0));
     VF_HIP_TRY(hipStreamWaitEvent(s, S.set_up, 0));
@@ -686,6 +687,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         }
 #undef VF_TILE_ARGS
     }
+    else VF_HIP_TRY(hipMemsetAsync(seg_count, 0, sizeof(uint32_t), s));   // (a shard without tiles: what k_clear does on its way in)
     if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipEventRecord(S.drawn, s));
     VF_HIP_TRY(hipGetLastError());
@@ -909,7 +911,7 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
 int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items, uint32_t *count)
 {
     if (!t || !dst || !count) return fail(VF_ERR_INVALID, "NULL argument");
-    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    if (!t->timing || !t->stats_on || !t->rendered) return fail(VF_ERR_INVALID, "statistics not enabled or nothing rendered");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
     uint32_t n = 0;
@@ -927,7 +929,7 @@ int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n)
     (void)n;
     return fail(VF_ERR_INVALID, "library built without -DVF_PHASE_PROF");
 #else
-    if (!t->timing || !t->rendered) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    if (!t->timing || !t->stats_on || !t->rendered) return fail(VF_ERR_INVALID, "statistics not enabled or nothing rendered");
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
     if (n > kPhaseSlots) n = kPhaseSlots;
@@ -940,6 +942,7 @@ int vf_terrain_enable_timing(vf_terrain *t, int enable)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     t->timing = enable != 0;
+    t->stats_on = enable == 1;   // 2: HIP events only -- the tile kernel runs exactly as it does untimed (no per-item statistics)
     t->timed_frames = 0;     // (re)start the averaging window
     return VF_OK;
 }
@@ -971,11 +974,12 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
         out->total_ms = span / (float)(nf - 1);
     }
     out->frames = nf;
-    uint32_t c[4];
-    VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));
-    out->blocks_rasterised = c[0];
+    out->blocks_rasterised = 0; out->blocks_distinct = 0;
     out->tiles = t->local_tiles;
-    {   // distinct blocks behind those pairs (last frame): the bitmap behind the per-item statistics
+    if (t->stats_on) {
+        uint32_t c[4];
+        VF_HIP_TRY(hipMemcpy(c, t->d_stats, sizeof c, hipMemcpyDeviceToHost));
+        out->blocks_rasterised = c[0];   // distinct blocks behind those pairs (last frame): the bitmap behind the per-item statistics
         std::vector<uint32_t> bits((t->nblocks + 31) / 32);
         VF_HIP_TRY(hipMemcpy(bits.data(), t->d_stats + 4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint32_t n = 0;

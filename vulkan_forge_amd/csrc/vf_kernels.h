@@ -934,6 +934,9 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                 // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer strips
                 while (lg && atomicAdd(split_budget, (1u << lg) - 1u) + (1u << lg) - 1u > kSplitBudget) { atomicSub(split_budget, (1u << lg) - 1u); --lg; }
             }
+#ifdef VF_DBG_FORCE_LG   // experiments only (tools/exp_slices.py): every busy tile cut the same way (0 only: no budget check)
+            lg = VF_DBG_FORCE_LG;
+#endif
             background[blockIdx.x] = lg << 8;               // busy; the strips it is cut into (read back with its time, above)
             const uint32_t parts = 1u << lg;
             const uint32_t at = atomicAdd(work_count, parts);
@@ -1144,7 +1147,13 @@ next_item:
     volatile uint32_t *v_pending = s_pending;
     volatile uint32_t *v_frontier = &s_frontier, *v_published = &s_published;
 
+#ifdef VF_DBG_SLICE_LO    // experiments only (tools/exp_slices.py): draw a depth slice of every tile's block rows (the picture is wrong)
+    const uint32_t dbg_first = nrows_total * VF_DBG_SLICE_LO / 256u;
+    nrows_total = nrows_total * VF_DBG_SLICE_HI / 256u;
+    for (uint32_t cursor = dbg_first; cursor < nrows_total;) {
+#else
     for (uint32_t cursor = 0; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
+#endif
         // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
         //      the ballots are kept for the fill pass ----
         const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
@@ -1407,14 +1416,29 @@ next_item:
 
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
     ShadeTables S = { s_lut, s_thr };
-    for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
-        const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
-        const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
-        if (px > T.px_hi || py > T.py_hi) continue;
-        const uint32_t id = s_vis[vis_index(lx, ly)];
-        const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-        rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
-        if (WRITE_VIS) vis_out[o] = id;
+    const int32_t item_w = T.px_hi - T.px_lo + 1;
+    if (item_w > 32 || (item_w & (item_w - 1)) != 0) {     // whole tiles, and tiles the target's right edge cuts
+        for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
+            const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
+            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
+            if (px > T.px_hi || py > T.py_hi) continue;
+            const uint32_t id = s_vis[vis_index(lx, ly)];
+            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
+            rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            if (WRITE_VIS) vis_out[o] = id;
+        }
+    } else {
+        // a strip (32, 16, 8 or 4 pixels wide): lanes run over the pixels of the strip, not of the 64 x 64 tile -- a 4-pixel strip is
+        // shaded by four waves in one trip, not by four lanes of every wave in four
+        const int32_t w_shift = 31 - __builtin_clz(item_w);
+        for (int k = tid; k < ((T.py_hi - T.py_lo + 1) << w_shift); k += kTileThreads) {
+            const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
+            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
+            const uint32_t id = s_vis[vis_index(lx, ly)];
+            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
+            rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            if (WRITE_VIS) vis_out[o] = id;
+        }
     }
     VF_PH(7)
     if (tid == 0) {
