@@ -160,7 +160,7 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 /* diagnostics (timing enabled): per work item of the last frame (a busy tile, or one column strip of a heavy tile), in
- * launch order, 4 words: item code (local tile | strip << 20 | log2(strips) << 24), candidate blocks processed,
+ * launch order, 4 words: item code (local tile | strip << 20 | log2(strips) << 24 | depth slice << 27 | log2(slices) << 29), candidate blocks processed,
  * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock).  *count = items written. */
 int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items, uint32_t *count);
 /* diagnostics, only in libraries built with -DVF_PHASE_PROF (VF_ERR_INVALID otherwise): shader-clock cycles summed over

@@ -231,6 +231,37 @@ def test_c4_full_size_properties(c4, oracle, cam):
     t.set_shard(0, 1, 64)
 
 
+def test_c4_rank_frames_while_the_plan_settles(c4, oracle, luts):
+    """One rank of eight (column stripes) at C4: its few far-field tiles are cut into up to 16 strips -- and, in a library built with
+    -DVF_SLICES=1, into depth slices (parts of the tile's descending block-row list, drawn by different workgroups and merged by
+    atomic max).  Every frame on the way from the cold plan to the settled one (whole tiles, then strips by tile time, then strips
+    ordered by their own times) equals the whole frame's tiles -- itself compared with the oracle in the next test."""
+    from vulkan_forge_amd import cabi as _cabi
+    t, h, W, H, G = c4
+    u = oracle.default_uniforms(1, W, H)
+    t.set_shard(0, 1, 64); t.set_uniforms(u); t.render()
+    whole = t.read_rgba()
+    sliced_items = cut_items = 0
+    try:
+        for r in (2, 5):
+            t.set_tile_shard(r, 8, 0)
+            lay = _cabi.tile_layout(W, H, r, 8, 0, lib=t.lib)
+            t.enable_timing(True)
+            for frame in range(7):
+                t.render()
+                tiles = t.read_tiles()
+                codes = t.item_stats()[:, 0]
+                sliced_items += int(((codes >> 29) & 3).astype(bool).sum())
+                cut_items += int(((codes >> 24) & 7).astype(bool).sum())
+                for k, (tx, ty) in enumerate(lay):
+                    assert np.array_equal(tiles[k], whole[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64]), (r, frame, tx, ty)
+            t.enable_timing(False)
+        assert cut_items > 0                                          # (sliced_items > 0 only with -DVF_SLICES=1)
+    finally:
+        t.enable_timing(False)
+        t.set_shard(0, 1, 64)
+
+
 def test_c4_default_camera_full_oracle_parity(c4, oracle, luts):
     t, h, W, H, G = c4
     u = oracle.default_uniforms(1, W, H)

@@ -20,9 +20,9 @@ for cam in ("default", "fill"):
         t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
         ms = it[:, 2] * 1e-5
         order = np.argsort(-ms)[:12]
-        print(f"{cam} rank {r}/{n}: total {tm['total_ms']:.3f} ms tile {tm['tile_ms']:.3f}; items {len(it)} (strips: {np.bincount(it[:,0] >> 24, minlength=5).tolist()} by log2) "
+        print(f"{cam} rank {r}/{n}: total {tm['total_ms']:.3f} ms tile {tm['tile_ms']:.3f}; items {len(it)} (strips: {np.bincount((it[:,0] >> 24) & 7, minlength=5).tolist()} by log2, slices: {np.bincount((it[:,0] >> 29) & 3, minlength=3).tolist()}) "
               f"pairs {it[:,1].sum()} sum item-ms {ms.sum():.1f} (/256 = {ms.sum()/256:.3f}) max {ms.max():.3f} p50 {np.median(ms):.3f}")
         for k in order:
-            code = int(it[k, 0]); tile = code & 0xFFFFF; part = (code >> 20) & 15; lg = code >> 24
+            code = int(it[k, 0]); tile = code & 0xFFFFF; part = (code >> 20) & 15; lg = (code >> 24) & 7; sl = (code >> 27) & 3; lgs = (code >> 29) & 3
             tx, ty = (tile % 64, tile // 64) if lay is None else lay[tile]
-            print(f"    item {k:5d}: tile ({tx},{ty}) strip {part}/{1 << lg} blocks={it[k,1]} raster_ms={ms[k]:.3f} frag_ms={(int(it[k,3])-int(it[k,2]))*1e-5:.3f} us/block={1e3*ms[k]/max(it[k,1],1):.2f}")
+            print(f"    item {k:5d}: tile ({tx},{ty}) strip {part}/{1 << lg} slice {sl}/{1 << lgs} blocks={it[k,1]} raster_ms={ms[k]:.3f} frag_ms={(int(it[k,3])-int(it[k,2]))*1e-5:.3f} us/block={1e3*ms[k]/max(it[k,1],1):.2f}")

@@ -119,7 +119,8 @@ struct vf_terrain {
         uint32_t *work_count = nullptr;  // [0] work items, [1] split budget used, [2] queue head, [3] items handed to the complete tile kernel
         uint32_t *redo = nullptr;        // those items (indices into work)
         uint32_t *background = nullptr;  // per local tile: bit 0 = no block row reaches it; bits 8.. = log2 of the strips it is cut into
-        uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later (+ [ntiles] = split quantum)
+        uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
+                                         // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
     } ps[2];
     hipStream_t side = nullptr;          // k_block_boxes -> k_plan -> k_plan_sort
@@ -131,6 +132,7 @@ struct vf_terrain {
     uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
     hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
+    uint32_t *d_merge = nullptr;         // where the depth slices of a heavy tile meet: [tiles][16] arrival counters, then [tiles][64 x 64] ids; zero between frames
     bool shard_tiles = false;
     uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
     uint32_t local_tiles = 0;            // tiles this handle renders (= ntx * local tile rows unless tile-sharded)
@@ -307,11 +309,11 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         A((void **)&S.cap_rad, t->nblocks * sizeof(float));
         A((void **)&S.rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
         A((void **)&S.work, (all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting
-        A((void **)&S.feedback, (all_tiles + 1) * sizeof(uint32_t));
+        A((void **)&S.feedback, (all_tiles * 65 + 1) * sizeof(uint32_t));
         A((void **)&S.work_count, 4 * sizeof(uint32_t));
         A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
         A((void **)&S.background, all_tiles * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles + 1) * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles * 65 + 1) * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemset(S.background, 0, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
@@ -323,6 +325,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
+    A((void **)&t->d_merge, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMemset(t->d_merge, 0, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
     A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t));   // + one bit per block: drawn this frame?
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
@@ -349,7 +353,7 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_rgba_scratch, t->d_diag };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_merge, t->d_rgba_scratch, t->d_diag };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
         void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
@@ -449,7 +453,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
-        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
     }
     return VF_OK;
@@ -491,7 +495,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->frames_since_reset = 0;
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
-        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty + 1) * sizeof(uint32_t)));
+        VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
     }
     return VF_OK;
@@ -672,12 +676,11 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         // one persistent workgroup per CU (a 1024-thread workgroup with 70 KB of LDS fills one), the fast variant, works through
         // the items; then a handful of persistent workgroups of the complete variant take the items that met a clipped or
         // oversized primitive (normally none)
-        uint32_t *redo_count = S.work_count + 3;
         const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount) * (1024u / (uint32_t)kTileThreads), ntiles + kSplitBudget)),
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
         const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
-                     rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, redo_count, S.redo
+                     rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
         if (write_vis) {
             hipLaunchKernelGGL((k_tile<true, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
             hipLaunchKernelGGL((k_tile<true, true>), few, threads, 0, s, VF_TILE_ARGS);

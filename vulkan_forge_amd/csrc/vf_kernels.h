@@ -856,10 +856,25 @@ __device__ __forceinline__ TilePlace tile_rect(const FrameParams &P, uint32_t ti
     return tp;
 }
 
-// work item = tile | part << 20 | log2(parts) << 24: a heavy tile is cut into 2, 4, 8 or 16 column strips, each its own
-// workgroup (blocks are only a few pixels wide, so narrow strips share little work)
+// work item = tile | part << 20 | log2(parts) << 24 | slice << 27 | log2(slices) << 29: a heavy tile is cut into 2, 4, 8 or 16
+// column strips (blocks are only a few pixels wide, so narrow strips share little work), and the heaviest ones also into 2 or 4
+// DEPTH SLICES -- consecutive parts of the tile's descending block-row list.  Every piece is a workgroup's item.  The slices of a
+// strip meet in the tile's words of the merge buffer (painter's order is a max over primitive ids, so the slices' tiles combine by
+// atomic max) and the slice that arrives last runs the fragment stage.  A slice culls against its own final pixels only: what
+// the slices in front of it cover it does not see, so slices repeat occluded work the way strips repeat block work -- the two
+// cuts together reach 64 pieces at about the repeated work of 16 strips (tools/exp_slices.py).
+// Depth slices are compiled out by default (VF_SLICES 0): on a rank of eight at C4 they shorten the longest item (0.21 -> 0.16 ms)
+// and still lengthen the frame (0.243 -> 0.263 ms) -- the ~25 us every item costs before its first block (row list, candidate tests,
+// list fill, fragment stage) times the extra items outweighs the shorter critical path.  tools/build_variant.sh x -DVF_SLICES=1
+// builds them in; tests/test_gpu_parity.py::test_c4_rank_frames_while_the_plan_settles checks them when they occur.
+#ifndef VF_SLICES
+#define VF_SLICES 0
+#endif
 constexpr uint32_t kSplitBudget = 2048;                    // extra work items a frame may create by splitting
 __device__ __forceinline__ uint32_t work_tile(uint32_t code) { return code & 0xFFFFFu; }
+__device__ __forceinline__ uint32_t work_part(uint32_t code) { return (code >> 20) & 15u; }
+__device__ __forceinline__ uint32_t work_slice(uint32_t code) { return (code >> 27) & 3u; }
+__device__ __forceinline__ uint32_t work_lg_slices(uint32_t code) { return (code >> 29) & 3u; }
 __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_t &px_hi)
 {
     const uint32_t lg = (code >> 24) & 7u, part = (code >> 20) & 15u;
@@ -905,7 +920,8 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             const bool as_one = P.nranks == 1u && !P.shard_tiles;
             auto tile_time = [&](uint32_t idx) -> uint32_t {
                 const uint32_t t = last_blocks[idx];
-                return as_one ? (uint32_t)(((unsigned long long)t * 4ull) / (4ull + (last_flags[idx] >> 8))) : t;
+                const uint32_t f = last_flags[idx];            // bits 8..11 log2(strips), 12..13 log2(slices) of the frame the time comes from
+                return as_one ? (uint32_t)(((unsigned long long)t * 4ull) / (4ull + ((f >> 8) & 15u) + ((f >> 12) & 3u))) : t;
             };
             uint32_t seen = tile_time(blockIdx.x);
             const uint32_t mean = *last_mean;
@@ -927,20 +943,39 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             // strips: 1, 2, 4, 8 or 16.  `mean` holds the split quantum published by k_plan_sort: four times the work one
             // item would carry if last frame's blocks were spread evenly over kTargetItems workgroups -- so a lightly loaded
             // GPU (one rank of a multi-GPU frame) cuts its few heavy tiles finer than a fully loaded one.
-            uint32_t lg = 0;
+            // Beyond 8 strips the next cuts are depth slices (2, then 4), and only then the 16th strip: 8-pixel strips in 2 slices
+            // repeat less work than 4-pixel strips, and their items are half as long.
+            uint32_t lg = 0, lgs = 0;
             if (mean && px_hi - px_lo + 1 == kTileW) {
                 const uint32_t q = seen / mean;
+#if VF_SLICES
+                lg = q >= 64u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
+                lgs = q >= 32u ? 2u : q >= 16u ? 1u : 0u;
+#else
                 lg = q >= 16u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
-                // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer strips
-                while (lg && atomicAdd(split_budget, (1u << lg) - 1u) + (1u << lg) - 1u > kSplitBudget) { atomicSub(split_budget, (1u << lg) - 1u); --lg; }
+#endif
+                // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer pieces
+                while (lg + lgs && atomicAdd(split_budget, (1u << (lg + lgs)) - 1u) + (1u << (lg + lgs)) - 1u > kSplitBudget) {
+                    atomicSub(split_budget, (1u << (lg + lgs)) - 1u);
+                    if (lgs) --lgs; else --lg;
+                }
             }
 #ifdef VF_DBG_FORCE_LG   // experiments only (tools/exp_slices.py): every busy tile cut the same way (0 only: no budget check)
-            lg = VF_DBG_FORCE_LG;
+            lg = VF_DBG_FORCE_LG; lgs = 0;
 #endif
-            background[blockIdx.x] = lg << 8;               // busy; the strips it is cut into (read back with its time, above)
-            const uint32_t parts = 1u << lg;
-            const uint32_t at = atomicAdd(work_count, parts);
-            for (uint32_t p = 0; p < parts; ++p) work[at + p] = make_uint2(blockIdx.x | (p << 20) | (lg << 24), weight >> lg);
+            // The pieces' weights order the launch (heaviest first).  Cut the way it was in the frame its time comes from, a tile
+            // hands every piece the time that piece took then (pieces differ: the slice in front draws more than the one behind,
+            // the strip over the ridge more than its neighbour); cut differently, the tile's time is shared evenly.
+            const uint32_t cut = lg | (lgs << 4);
+            const bool same_cut = seen == tile_time(blockIdx.x) && seen != 0u && ((last_flags[blockIdx.x] >> 8) & 0x3Fu) == cut;
+            const uint32_t *piece_time = last_blocks + (size_t)P.ntx * P.nty + 1u + (size_t)blockIdx.x * 64u;
+            background[blockIdx.x] = cut << 8;              // busy; the pieces it is cut into (read back with its time, above)
+            const uint32_t parts = 1u << lg, slices = 1u << lgs;
+            const uint32_t at = atomicAdd(work_count, parts * slices);
+            for (uint32_t p = 0; p < parts; ++p)
+                for (uint32_t sl = 0; sl < slices; ++sl)
+                    work[at + p * slices + sl] = make_uint2(blockIdx.x | (p << 20) | (lg << 24) | (sl << 27) | (lgs << 29),
+                                                            same_cut ? max(piece_time[p * slices + sl], 1u) : weight >> (lg + lgs));
         }
         return;
     }
@@ -1044,9 +1079,10 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
                                                        const uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                                        const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
-                                                       uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo_count,
-                                                       uint32_t *__restrict__ redo)
+                                                       uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo,
+                                                       uint32_t *__restrict__ merge)
 {
+    uint32_t *const redo_count = work_count + 3;           // items handed to the complete variant
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
@@ -1147,13 +1183,24 @@ next_item:
     volatile uint32_t *v_pending = s_pending;
     volatile uint32_t *v_frontier = &s_frontier, *v_published = &s_published;
 
-#ifdef VF_DBG_SLICE_LO    // experiments only (tools/exp_slices.py): draw a depth slice of every tile's block rows (the picture is wrong)
-    const uint32_t dbg_first = nrows_total * VF_DBG_SLICE_LO / 256u;
-    nrows_total = nrows_total * VF_DBG_SLICE_HI / 256u;
-    for (uint32_t cursor = dbg_first; cursor < nrows_total;) {
+    // a depth slice draws its part of the row list (the complete variant redraws the whole strip, whichever slice filed it)
+#if VF_SLICES
+    const uint32_t lg_slices = COMPLETE ? 0u : work_lg_slices(item);
 #else
-    for (uint32_t cursor = 0; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
+    constexpr uint32_t lg_slices = 0u;
 #endif
+    uint32_t row_first = 0;
+#if VF_SLICES
+    if (lg_slices) {
+        row_first = (nrows_total * work_slice(item)) >> lg_slices;
+        nrows_total = (nrows_total * (work_slice(item) + 1u)) >> lg_slices;
+    }
+#endif
+#ifdef VF_DBG_SLICE_LO    // experiments only (tools/exp_slices.py): draw a depth slice of every tile's block rows (the picture is wrong)
+    row_first = nrows_total * VF_DBG_SLICE_LO / 256u;
+    nrows_total = nrows_total * VF_DBG_SLICE_HI / 256u;
+#endif
+    for (uint32_t cursor = row_first; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
         // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
         //      the ballots are kept for the fill pass ----
         const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
@@ -1414,9 +1461,41 @@ next_item:
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
 
+    const int32_t item_w = T.px_hi - T.px_lo + 1;
+#if VF_SLICES
+    bool shade = true;
+    if (lg_slices) {                                        // (uniform)
+        // ---- depth slices meet in the tile's words of the merge buffer: max of the ids; the last one to arrive takes the result
+        //      (and leaves the words zero for the next frame) ----
+        uint32_t *const mcount = merge + (tile * 16u + work_part(item));                       // [all tiles][16 strips]
+        uint32_t *const mtile = merge + (size_t)P.ntx * P.nty * 16u + (size_t)tile * (kTileW * kTileH) + (uint32_t)(T.px_lo - tile_x0);
+        const int32_t w_shift = 31 - __builtin_clz(item_w);                                    // (sliced tiles are whole tiles: item_w = 64 >> lg)
+        const int32_t npx = (T.py_hi - T.py_lo + 1) << w_shift;
+        for (int k = tid; k < npx; k += kTileThreads) {
+            const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
+            const uint32_t id = s_vis[vis_index(lx, ly)];
+            if (id) atomicMax(&mtile[ly * kTileW + lx], id);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_item = atomicAdd(mcount, 1u);
+        __syncthreads();
+        shade = s_item == (1u << lg_slices) - 1u;
+        if (shade) {
+            if (tid == 0) *mcount = 0u;
+            for (int k = tid; k < npx; k += kTileThreads) {
+                const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
+                s_vis[vis_index(lx, ly)] = atomicExch(&mtile[ly * kTileW + lx], 0u);
+            }
+        }
+        __syncthreads();
+    }
+#else
+    constexpr bool shade = true;
+#endif
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
     ShadeTables S = { s_lut, s_thr };
-    const int32_t item_w = T.px_hi - T.px_lo + 1;
+    if (shade) {
     if (item_w > 32 || (item_w & (item_w - 1)) != 0) {     // whole tiles, and tiles the target's right edge cuts
         for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
             const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
@@ -1440,10 +1519,13 @@ next_item:
             if (WRITE_VIS) vis_out[o] = id;
         }
     }
+    }
     VF_PH(7)
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
+        if (!COMPLETE)                                        // ... and this piece of it (behind the tile times and the quantum word)
+            last_blocks[(size_t)P.ntx * P.nty + 1u + (size_t)tile * 64u + (work_part(item) << lg_slices) + work_slice(item)] = max(ticks, 1u);
         if (stats) stats[7 + 4 * item_idx] = ticks;        // raster + fragment phase
         if (!COMPLETE && s_redo) redo[atomicAdd(redo_count, 1u)] = item_idx;   // this item met a primitive the fast path skips
     }
