@@ -53,7 +53,7 @@ open(os.path.join(P, f"{prefix}_rehearse_4ranks.json"), "w").write(last_json_lin
 copy("kernel_stats.csv", "kernel_stats.csv")
 for n in ("fetch_default", "write_default", "frag_fetch", "frag_write"):
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
-for n in ("ranks.log", "rank_timeline.log", "top_items.log"):
+for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log"):
     copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
 

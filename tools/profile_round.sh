@@ -30,5 +30,6 @@ pmc frag_write "WRITE_SIZE" "$R/tools/exp_fragment.py" || exit 1
 echo "== ranks"; timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0 4:0 8:0 8:3 > "$out/ranks.log" 2>&1; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0 4:0 8:0 8:3 >> "$out/ranks.log" 2>&1; cat "$out/ranks.log"
 tools/prof_rank.sh $tag/rank_trace 2 8 0 > "$out/rank_timeline.log" 2>&1; tail -3 "$out/rank_timeline.log"
 timeout -k 10 300 python tools/exp_toptiles.py > "$out/top_items.log" 2>&1
+timeout -k 10 300 python tools/exp_rank_frames.py 2 8 > "$out/rank_frames.log" 2>&1; grep period "$out/rank_frames.log"
 echo "== rehearsal"; timeout -k 10 600 python bench.py --gpus 4 --rehearse --check --no-cpu-baseline --steps 5 > "$out/rehearse_4ranks.json" 2> "$out/rehearse_4ranks.err"; tail -c 300 "$out/rehearse_4ranks.json"
 echo "== done"
