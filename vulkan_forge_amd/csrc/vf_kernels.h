@@ -1096,6 +1096,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
     __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
     __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
+    __shared__ uint16_t s_words[kMaxSteps];                // per step: first | end << 8 of the 64-block groups its ballots were taken for
     __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
     __shared__ uint32_t s_firstid[kMaxSteps];
     __shared__ uint16_t s_allrows[1024];                   // block rows that reach the tile, descending (nb <= 1024)
@@ -1227,10 +1228,6 @@ next_item:
 #pragma unroll
             for (int r = 0; r < kRowsAtOnce; ++r)
                 if (bx_lo[r] < bx_hi[r]) { g_first = min(g_first, bx_lo[r] >> 6); g_last = max(g_last, ((bx_hi[r] - 1u) >> 6) + 1u); }
-            for (uint32_t g = lane; g < hit_words * kRowsAtOnce; g += 64u) {       // ballots of the groups outside: none
-                const uint32_t k = k0 + (g / hit_words) * kWaves, gg = g % hit_words;
-                if (k < nrowsteps && (gg < g_first || gg >= g_last)) s_hit[k][gg] = 0ull;
-            }
             for (uint32_t g = g_first; g < g_last; ++g) {
                 const uint32_t bx = g * 64u + lane;
                 PixelBox box[kRowsAtOnce];
@@ -1258,7 +1255,8 @@ next_item:
 #pragma unroll
             for (int r = 0; r < kRowsAtOnce; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * kWaves;
-                if (lane == 0 && k < nrowsteps) { s_cnt[k] = cnt[r]; s_firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+                // (the list fill reads the ballots of groups g_first .. g_last - 1 only: the others are never written)
+                if (lane == 0 && k < nrowsteps) { s_cnt[k] = cnt[r]; s_words[k] = (uint16_t)(g_first < g_last ? g_first | (g_last << 8) : 0u); s_firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
             }
         }
         VF_PH(9)                                            // candidate tests
@@ -1287,7 +1285,8 @@ next_item:
             const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]);
             uint32_t pos = (uint32_t)(k < 64u ? __builtin_amdgcn_readlane((int)(inc0 - c0), (int)k) : __builtin_amdgcn_readlane((int)(inc1 - c1), (int)k - 64));
             uint32_t cnt = 0;
-            for (uint32_t g = 0; g < hit_words; ++g) {
+            const uint32_t words = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_words[k]);
+            for (uint32_t g = words & 0xFFu; g < (words >> 8); ++g) {
                 const unsigned long long m = s_hit[k][g];
                 if ((m >> lane) & 1ull) s_list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
                 const uint32_t c = (uint32_t)__popcll(m);
