@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
     __shared__ uint32_t s_firstid[kMaxSteps];
     __shared__ uint16_t s_allrows[1024];                   // block rows that reach the tile, descending (nb <= 1024)
+    __shared__ uint32_t s_rc[1024];                        // per block row: first | end << 16 of the blocks that can reach this tile column (kept from the row mask pass)
     __shared__ uint32_t s_colfin[kTileW * 2];
     __shared__ uint32_t s_rowfin[kTileH * 2];
     __shared__ uint32_t s_part[kWaves];
@@ -1153,8 +1154,9 @@ next_item:
         bool hit = false;
         if (r < P.nb) {
             const PixelBox rr = row_boxes[r];
-            hit = rc_lo[tcol * P.nb + r] < rc_hi[tcol * P.nb + r] && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi &&
-                  rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
+            const uint32_t lo = rc_lo[tcol * P.nb + r], hi = rc_hi[tcol * P.nb + r];
+            s_rc[r] = lo < hi ? lo | (hi << 16) : 1u;                  // (1 = the empty range [1, 0))
+            hit = lo < hi && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi && rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
         }
         const unsigned long long m = __ballot(hit);
         if (lane == 0 && m) s_rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
@@ -1180,6 +1182,9 @@ next_item:
     __syncthreads();
 
     VF_PH(8)                                                // item start, tile state, row list
+#ifdef VF_DBG_LOOPTIME
+    uint32_t dbg_loop = 0;
+#endif
     const uint32_t hit_words = (P.nb + 63u) / 64u;
     volatile uint32_t *v_pending = s_pending;
     volatile uint32_t *v_frontier = &s_frontier, *v_published = &s_published;
@@ -1220,8 +1225,9 @@ next_item:
                 const bool valid = k < nrowsteps;
                 by[r] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]) : 0u;
                 // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
-                bx_lo[r] = valid ? rc_lo[tcol * P.nb + by[r]] : 1u;
-                bx_hi[r] = valid ? rc_hi[tcol * P.nb + by[r]] : 0u;
+                const uint32_t range = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rc[by[r]]) : 1u;
+                bx_lo[r] = range & 0xFFFFu;
+                bx_hi[r] = range >> 16;
                 cnt[r] = 0u;
             }
             uint32_t g_first = hit_words, g_last = 0;                 // groups of 64 blocks that hold any block of the four ranges
@@ -1301,6 +1307,9 @@ next_item:
 
         // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
         uint32_t my_blocks = 0;
+#ifdef VF_DBG_LOOPTIME
+        const uint64_t dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (;;) {
             // (a finished tile pushes the list counter past the list's end: one LDS round trip tells "nothing left" and "tile final" apart
             //  from "here is your block" -- a separate look at a done flag was one more dependent round trip per block: -1.6 %)
@@ -1433,6 +1442,9 @@ next_item:
         VF_PH(1)
         if (lane == 0 && my_blocks) atomicAdd(&s_blocks, my_blocks);
         __syncthreads();
+#ifdef VF_DBG_LOOPTIME
+        dbg_loop += (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
+#endif
         if (s_done) break;                                             // uniform
         // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
         {
@@ -1456,7 +1468,11 @@ next_item:
     VF_PH(6)
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
+#ifdef VF_DBG_LOOPTIME
+        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = dbg_loop;     // (experiment: ticks inside the block loops instead of the block count)
+#else
         stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_blocks;
+#endif
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
 
