@@ -878,7 +878,8 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (err == hipSuccess) err = hipEventCreate(&e0);
     if (err == hipSuccess) err = hipEventCreate(&e1);
-    const dim3 grid(((t->W + 255u) / 256u) * t->H), threads(256);
+    const uint32_t per_cu = 8;                                          // resident 256-thread workgroups per CU (persistent, grid stride)
+    const dim3 grid(std::min<uint32_t>(((t->W + 255u) / 256u) * t->H, (uint32_t)std::max(1, t->ctx->prop.multiProcessorCount) * per_cu)), threads(256);
     const vf_terrain::PlanState &S = t->ps[(t->frame_no - 1u) & 1u];     // the set-up of the frame just rendered
     const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
     auto launch = [&](uint32_t *covered) {
