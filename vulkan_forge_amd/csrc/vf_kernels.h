@@ -291,6 +291,18 @@ __device__ __forceinline__ uint32_t wave_reduce_pk_i16(uint32_t v)
     return v;
 }
 
+// inclusive prefix sum across the wave by DPP (no LDS round trips): within the rows of 16, then row totals into the rows behind
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1 (lanes without a source add 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
                                                                const PixelBox *__restrict__ cons_boxes, VertexRec *__restrict__ vtx,
                                                                BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen,
@@ -1093,7 +1105,10 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
-    constexpr int kMaxSteps = 128;                         // block rows per chunk
+#ifndef VF_MAX_STEPS
+#define VF_MAX_STEPS 128
+#endif
+    constexpr int kMaxSteps = VF_MAX_STEPS;                // block rows per chunk
     constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
     constexpr int kRescanEvery = VF_RESCAN_EVERY;          // publish new masks when the frontier moved this many steps
     __shared__ uint32_t s_vis[kTileW * kTileH];
@@ -1275,28 +1290,36 @@ next_item:
         VF_PH(9)                                            // candidate tests
         __syncthreads();
         VF_PH(10)                                           // ... waiting for the slowest wave
-        // ---- chunk set-up 2: every wave scans the row counts for itself (two 64-row halves), so all agree on the list offsets
+        // ---- chunk set-up 2: every wave scans the row counts for itself (64 rows at a time, DPP), so all agree on the list offsets
         //      and on how many rows fit the list without another barrier; rows that do not fit wait for the next chunk ----
-        static_assert(kMaxSteps == 128, "the offset scan below handles two 64-row halves");
-        const uint32_t c0 = lane < nrowsteps ? s_cnt[lane] : 0u, c1 = lane + 64u < nrowsteps ? s_cnt[lane + 64u] : 0u;
-        uint32_t inc0 = c0, inc1 = c1;
+        constexpr int kParts = kMaxSteps / 64;              // the rows of a chunk, 64 (one per lane) at a time
+        static_assert(kMaxSteps % 64 == 0 && kParts >= 1 && kParts <= 4, "the offset scan below works on 64-row parts");
+        uint32_t c[kParts], inc[kParts];
+        unsigned long long fm[kParts];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t0 = __shfl_up(inc0, o), t1 = __shfl_up(inc1, o);
-            if (lane >= (uint32_t)o) { inc0 += t0; inc1 += t1; }
+        for (int p = 0; p < kParts; ++p) {
+            c[p] = lane + 64u * p < nrowsteps ? s_cnt[lane + 64u * p] : 0u;
+            inc[p] = wave_scan_add(c[p]);
+            if (p) inc[p] += (uint32_t)__builtin_amdgcn_readlane((int)inc[p - 1], 63);
+            fm[p] = __ballot(lane + 64u * p < nrowsteps && inc[p] <= kChunk);
         }
-        inc1 += (uint32_t)__builtin_amdgcn_readlane((int)inc0, 63);
-        const unsigned long long fm0 = __ballot(lane < nrowsteps && inc0 <= kChunk), fm1 = __ballot(lane + 64u < nrowsteps && inc1 <= kChunk);
         // rows are admitted in order: stop at the first one that does not fit (a single row always fits: nb <= 1024 < kChunk)
-        const uint32_t nsteps = fm0 != ~0ull ? (uint32_t)__builtin_ctzll(~fm0) : 64u + (fm1 != ~0ull ? (uint32_t)__builtin_ctzll(~fm1) : 64u);
+        uint32_t nsteps = 64u * kParts;
+#pragma unroll
+        for (int p = kParts - 1; p >= 0; --p) if (fm[p] != ~0ull) nsteps = 64u * p + (uint32_t)__builtin_ctzll(~fm[p]);
         // wave-uniform values are read with readlane / readfirstlane so that they, and the addresses derived from them, live in
         // scalar registers: the vector register file is the scarce resource of this kernel
-        const uint32_t nlist = (uint32_t)(nsteps <= 64u ? __builtin_amdgcn_readlane((int)inc0, (int)nsteps - 1)
-                                                         : __builtin_amdgcn_readlane((int)inc1, (int)nsteps - 65));
+        auto row_value = [&](const uint32_t (&v)[kParts], uint32_t k) -> uint32_t {      // v of row k (k wave-uniform)
+            uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v[0], (int)(k & 63u));
+#pragma unroll
+            for (int p = 1; p < kParts; ++p) if ((k >> 6) == (uint32_t)p) r = (uint32_t)__builtin_amdgcn_readlane((int)v[p], (int)(k & 63u));
+            return r;
+        };
+        const uint32_t nlist = row_value(inc, nsteps - 1u);
         // ---- chunk set-up 3: fill the work list from the kept ballots ----
         for (uint32_t k = wave; k < nsteps; k += kWaves) {
             const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]);
-            uint32_t pos = (uint32_t)(k < 64u ? __builtin_amdgcn_readlane((int)(inc0 - c0), (int)k) : __builtin_amdgcn_readlane((int)(inc1 - c1), (int)k - 64));
+            uint32_t pos = row_value(inc, k) - row_value(c, k);
             uint32_t cnt = 0;
             const uint32_t words = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_words[k]);
             for (uint32_t g = words & 0xFFu; g < (words >> 8); ++g) {
