@@ -1128,6 +1128,9 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
     __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
+#ifdef VF_DBG_PULLS
+    __shared__ uint32_t s_dbg;
+#endif
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
 
@@ -1168,6 +1171,9 @@ next_item:
     for (int k = tid; k < kTileH * 2; k += kTileThreads) s_rowfin[k] = 0u;
     if (tid < 16) s_rows[tid] = 0ull;
     if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
+#ifdef VF_DBG_PULLS
+    if (tid == 0) s_dbg = 0;
+#endif
     __syncthreads();
     VF_PH(13)                                              // item record, tile state
     // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
@@ -1347,6 +1353,9 @@ next_item:
             if (lane == 0) idx = atomicAdd(&s_next, 1u);
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
             if (idx >= nlist) break;
+#ifdef VF_DBG_PULLS
+            if (lane == 0) atomicAdd(&s_dbg, 1u);            // (experiment: blocks pulled, live or not)
+#endif
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
             // One round trip for everything the block needs from HBM: its record (pixel box, alive masks) and its 81 snapped
@@ -1500,6 +1509,8 @@ next_item:
         atomicAdd(&stats[0], s_blocks);
 #ifdef VF_DBG_LOOPTIME
         stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = dbg_loop;     // (experiment: ticks inside the block loops instead of the block count)
+#elif defined(VF_DBG_PULLS)
+        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_dbg;        // (experiment: blocks pulled instead of blocks drawn)
 #else
         stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_blocks;
 #endif
