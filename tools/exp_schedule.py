@@ -7,7 +7,7 @@ from vulkan_forge_amd import cabi
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 W = H = G = 4096
-lut = np.load("tests/golden/colormaps_rgba8.npz")["viridis"]
+import vulkan_forge_amd as _vf; lut = _vf.colormap_rgba8("viridis")
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, lut); t.set_height(h)
 

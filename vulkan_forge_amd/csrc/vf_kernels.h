@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // needs no clipping and is not oversized -- all of them in ordinary views -- and files an item that met one of the others
 // in `redo`.  COMPLETE = true is a small persistent launch that renders the filed items again, this time with the generic
 // path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
-// of the main kernel leaves it without scratch memory and without a single spilled vector register.
+// of the main kernel is what lets it live in 96 vector registers (VF_TILE_MIN_WAVES, vf_device.h: the next frame's set-up kernel
+// shares the CUs with it); the 28 registers it spills at that cap are spilled outside the block loop.
 template <bool WRITE_VIS, bool COMPLETE>
 __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameParams P, SetupView V, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
