@@ -325,8 +325,10 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     A((void **)&t->d_lut, sizeof lut);
     A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
+#if VF_SLICES   // (depth slices are compiled out by default, vf_kernels.h: no merge buffer then)
     A((void **)&t->d_merge, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemset(t->d_merge, 0, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
+#endif
     A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t));   // + one bit per block: drawn this frame?
     if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
