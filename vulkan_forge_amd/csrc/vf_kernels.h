@@ -1134,6 +1134,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
 #endif
     __shared__ float s_lut[256 * 3];
     __shared__ float s_thr[256];
+    __shared__ uint32_t s_per[65];                         // [survivors]: lanes per survivor | ceil(2^16 / that) << 7 | survivors per round << 24
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
+    if (tid <= 64u) { const uint32_t per = tid ? 64u / tid : 64u; s_per[tid] = per | (((65536u + per - 1u) / per) << 7) | ((64u / per) << 24); }
     const uint32_t nwork = *work_count;
     uint32_t pulled = 0;
     if (!COMPLETE) {
@@ -1436,20 +1438,22 @@ next_item:
                 VF_PH(3)
                 // ---- pass B: the survivors share the wave: with few of them, 2..64 lanes split the lines of one triangle ----
                 {
-                    uint32_t per = 1;                                   // lanes per survivor: largest power of two <= 64 / nsurv
-                    while (per < 64u && per * 2u * nsurv <= 64u) per *= 2u;
-                    const uint32_t shift = (uint32_t)__builtin_ctz(per);
-                    for (uint32_t sbase = 0; sbase < nsurv; sbase += 64u >> shift) {
+                    // lanes per survivor: floor(64 / nsurv) -- any number, not only powers of two (17 survivors: 3 lanes each, not 2);
+                    // lane / per by a 16-bit reciprocal from a table in LDS (exact for lane < 64)
+                    const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_per[min(nsurv, 64u)]);
+                    const uint32_t per = pe & 0x7Fu, group = pe >> 24;          // group = survivors per round = 64 / per
+                    const uint32_t q = (lane * ((pe >> 7) & 0x1FFFFu)) >> 16, sub = lane - q * per;
+                    for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {
                         VF_RC(if (lane == 0) rc_iters++;)
-                        const uint32_t sidx = sbase + (lane >> shift);
-                        if (sidx < nsurv) {
+                        const uint32_t sidx = sbase + q;
+                        if (q < group && sidx < nsurv) {
                             const uint32_t code = sS[wave][sidx];
                             const uint32_t cell = code >> 1, odd = code & 1u;
                             const uint32_t lj = cell >> 3, li = cell & 7u;
                             const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)(lane & (per - 1u)), (int32_t)per VF_RC(, RC));
+                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)sub, (int32_t)per VF_RC(, RC));
                         }
                     }
                 }
