@@ -2,17 +2,27 @@
 //
 //   k_axis_tables     once per (grid, texture size): per-column / per-row vertex-shader terms
 //   k_height_blocks   once per height upload: displaced-height cache (9x9 heights per 8x8-cell block) + block min/max
-//   k_block_boxes     per frame: conservative pixel rectangle of every block (+ per block row)
-//   k_tile            per frame: one workgroup per 64x64 screen tile.  Walks the block rows that can
-//                     touch the tile in DESCENDING primitive order; each wave takes one candidate
-//                     block, rebuilds its 9x9 vertex tile in LDS, sets its 128 triangles up and
-//                     rasterises them with exact FP64 span solving into an LDS visibility tile
-//                     (ds_max_u32).  After every block row the covered pixels are final; final-pixel
-//                     masks cull occluded blocks, lines and pixels, and a fully final tile stops early.
-//                     The fragment stage then runs on the LDS tile and stores RGBA8 -- no
-//                     framebuffer-sized intermediate ever touches HBM.
+//   per frame, on the handle's side streams (they touch plan state only and run under the previous frame's tile kernel):
+//   k_block_boxes     conservative pixel rectangle + capsule of every block, block ranges per (block row, tile column); on a
+//                     shard: drops the blocks that reach none of the rank's tiles, lists the 16-block segments still needed
+//   k_block_setup     vs_main + the tile-independent part of primitive assembly / culling, once per block: 81 vertex records
+//                     {X, Y, 1/w, h} and a block record (exact pixel box, alive masks) per block
+//   k_plan, k_plan_sort   busy tiles -> work items weighted by last frame's measured times, heavy tiles cut into column
+//                     strips, heaviest first
+//   per frame, on the caller's stream:
+//   k_clear           background tiles <- clear colour
+//   k_tile            persistent workgroups pull work items (a 64x64 screen tile or a strip of one).  Per item: the block rows
+//                     that can touch the tile in DESCENDING primitive order, in chunks; waves pull candidate blocks, load
+//                     their records, classify the alive primitives against the tile and its final-pixel masks and rasterise
+//                     the survivors with the FP32-first exact span solver of vf_raster.h into an LDS visibility tile
+//                     (ds_max_u32).  After every block row the covered pixels are final; final-pixel masks cull occluded
+//                     blocks, lines and pixels, and a fully final tile stops early.  The fragment stage then runs on the LDS
+//                     tile and stores RGBA8 -- no framebuffer-sized intermediate ever touches HBM.  Two instantiations:
+//                     the fast one (no clipping code) and the complete one for the rare items that need it.
+//   k_resolve         diagnostics: the fragment stage as a launch of its own
 //   k_grid_*          grid_generate (bit-exact make_grid)
 //   k_triangle        the triangle smoke path
+//   k_dem_*           Renderer DEM path: ingest, statistics, normalisation, sampling
 //   k_stitch_bands / k_stitch_tiles   multi-GPU de-interleave
 //   k_png_filter      render_png read-back: PNG scanline filtering
 //
@@ -20,6 +30,10 @@
 // visible fragment is the LAST covering front-facing primitive in index order == max primitive id.
 // Primitive ids are cell-row major, so every primitive of block row r+1 beats every primitive of
 // block row r: after a block row has been rasterised, covered pixels are final.
+//
+// Build-time switches (defaults are the measured optimum at C4; DESIGN.md section 7 has the sweeps): VF_TILE_MIN_WAVES (vf_device.h: the
+// tile kernel's register cap), VF_SPLIT_QUANTUM_X4, VF_RESCAN_EVERY, VF_CLS_LINES, VF_ROWS_AT_ONCE, VF_MAX_STEPS; VF_SLICES=1 compiles
+// the depth slices in; VF_PHASE_PROF the per-phase cycle counters; VF_DBG_* single-purpose experiment hooks of tools/exp_*.py.
 #pragma once
 #include "vf_device.h"
 #include "vf_raster.h"
