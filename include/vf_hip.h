@@ -51,15 +51,15 @@ typedef struct vf_device_info {
     int32_t pci_device_id;
 } vf_device_info;
 
-/* device time (HIP events), averaged over the frames rendered since vf_terrain_enable_timing(t, 1) -- at most the last 64.
+/* device time (HIP events), averaged over the frames rendered since vf_terrain_enable_timing(t, 1 or 2) -- at most the last 64.
  * A frame's plan kernels run on a stream of the handle's own and overlap the previous frame's tile kernel, so the first two
  * figures are elapsed times on that stream (they include waiting for free CUs when frames are rendered back to back). */
 typedef struct vf_timings {
-    float ranges_ms;    /* k_block_boxes: per-block pixel boxes and capsules (side stream, elapsed) */
+    float ranges_ms;    /* k_block_boxes (per-block pixel boxes and capsules) up to the launch of k_block_setup (side stream, elapsed) */
     float plan_ms;      /* k_plan + k_plan_sort: background flags, busy-tile list, heaviest first (side stream, elapsed) */
-    float tile_ms;      /* k_clear + k_tile on the caller's stream: background clear, vertex + setup + LDS raster + fragment stage */
+    float tile_ms;      /* k_clear + k_tile (both variants) on the caller's stream: background clear, LDS raster from the set-up pass's records, fragment stage */
     float total_ms;     /* frame period when >= 2 frames were timed back to back, else plan start -> RGBA8 complete */
-    uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out) */
+    uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out); 0 at timing level 2 */
     uint32_t tiles;             /* workgroups launched = owned screen tiles */
     uint32_t frames;            /* frames averaged */
     uint32_t blocks_distinct;   /* distinct grid blocks behind blocks_rasterised in the last frame (of grid blocks in total: ceil((n-1)/8)^2) */
