@@ -897,7 +897,7 @@ __device__ __forceinline__ TilePlace tile_rect(const FrameParams &P, uint32_t ti
 // the slices in front of it cover it does not see, so slices repeat occluded work the way strips repeat block work -- the two
 // cuts together reach 64 pieces at about the repeated work of 16 strips (tools/exp_slices.py).
 // Depth slices are compiled out by default (VF_SLICES 0): on a rank of eight at C4 they shorten the longest item (0.21 -> 0.16 ms)
-// and still lengthen the frame (0.243 -> 0.263 ms) -- the ~25 us every item costs before its first block (row list, candidate tests,
+// and still lengthen the frame (0.225 -> 0.249 ms) -- the ~25 us every item costs before its first block (row list, candidate tests,
 // list fill, fragment stage) times the extra items outweighs the shorter critical path.  tools/build_variant.sh x -DVF_SLICES=1
 // builds them in; tests/test_gpu_parity.py::test_c4_rank_frames_while_the_plan_settles checks them when they occur.
 #ifndef VF_SLICES
