@@ -108,6 +108,14 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
 #define VF_SHADE_REFERENCE 0
 #define VF_SHADE_SPEC_T32 1
 int vf_terrain_set_shade_mode(vf_terrain *t, int mode);
+/* Fragment-stage arithmetic (new; the reference leaves it to the driver's shader compiler, src/shaders/terrain.wgsl:69-91).
+ * VF_PRECISION_FAST (default): hardware reciprocal / rsq / sin / cos / log / exp and fused multiply-adds -- visibility is
+ * unaffected, RGBA stays within 1 LSB per channel of VF_PRECISION_EXACT (BASELINE.json: "RGBA within +-1 LSB of reference"),
+ * which evaluates every operation as a correctly rounded IEEE binary32 one in a fixed order and reproduces the CPU oracle bit
+ * for bit.  VF_SHADE_SPEC_T32 frames are always drawn with the exact arithmetic. */
+#define VF_PRECISION_EXACT 0
+#define VF_PRECISION_FAST 1
+int vf_terrain_set_shade_precision(vf_terrain *t, int precision);
 
 /* Multi-GPU screen split (new; the reference is single-device).  Pixel row y belongs to this
  * object iff ((y / band_h) % nranks) == rank; owned rows are stored densely ("local rows") in
@@ -151,7 +159,10 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
  * bytes -- in pinned host memory owned by the handle (allocated once, not per call as the reference's read-back buffer
  * :446-451), valid until the next call on the handle.  The host only deflates.  Whole-frame handles only. */
 int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines, size_t *nbytes);
-/* debug/parity: per-pixel visible primitive id + 1 (0 = background) of the last render, local rows */
+/* debug/parity: per-pixel visible primitive id + 1 (0 = background), local rows.  The visibility tile never leaves LDS in a
+ * normal frame, so this draws a frame again into scratch buffers: the frame vf_terrain_render drew last (its uniforms and
+ * shade mode, whatever was set since), or -- before the first vf_terrain_render on this shard layout -- the current uniforms.
+ * The caller's output buffer and the `rendered` state are left as they were. */
 int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 
 /* enable: 0 off; 1 device times (HIP events around the frame's kernels) and the per-item statistics behind
@@ -159,6 +170,11 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
  * 2 device times only -- the kernels run exactly as they do untimed (what bench.py times; blocks_* read 0). */
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
+/* The same HIP events frame by frame (timing enabled; the frames since vf_terrain_enable_timing, at most the last 64, oldest
+ * first): tile_ms[f] = k_clear + k_tile of frame f on the caller's stream, period_ms[f] = end of frame f - 1 -> end of frame f
+ * (frames rendered back to back overlap: the period is what a frame costs; period_ms[0] = 0).  Either array may be NULL.
+ * For the median / p95 report of python/tools/perf_sanity.py:45-69. */
+int vf_terrain_frame_times(vf_terrain *t, float *tile_ms, float *period_ms, uint32_t max_frames, uint32_t *count);
 /* diagnostics (timing enabled): per work item of the last frame (a busy tile, or one column strip of a heavy tile), in
  * launch order, 4 words: item code (local tile | strip << 20 | log2(strips) << 24 | depth slice << 27 | log2(slices) << 29), candidate blocks processed,
  * raster-phase time, raster+fragment time (10 ns ticks of the constant 100 MHz clock).  *count = items written. */
@@ -231,8 +247,13 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
 int vf_dist_available(void);                                   /* 1 when RCCL could be resolved in this process */
 int vf_dist_unique_id(uint8_t id[VF_DIST_UNIQUE_ID_BYTES]);    /* ncclGetUniqueId */
 int vf_dist_comm_init(vf_ctx *ctx, const uint8_t id[VF_DIST_UNIQUE_ID_BYTES], int rank, int nranks, void **comm);   /* ncclCommInitRank on ctx's device */
-void vf_dist_comm_destroy(void *comm);
-/* Tile shards -> rank `root`, point to point (every sender on its own xGMI link to the root, no ring): one
+void vf_dist_comm_destroy(void *comm);                         /* ncclCommDestroy on the communicator's own device */
+/* Every rank of the communicator calls the gather with the SAME root, stride_tiles and shard layout.  What a rank can check
+ * locally (handle sharded and rendered, communicator rank/size == the handle's shard, root in range, stride_tiles >= the
+ * largest shard of the layout) is checked on every rank before anything is posted, so all ranks fail together.  The root's
+ * buffer pointer can only be checked on the root: a root that passes NULL returns VF_ERR_INVALID while the other ranks have
+ * queued their sends and wait -- pass a valid buffer.
+ * Tile shards -> rank `root`, point to point (every sender on its own xGMI link to the root, no ring): one
  * ncclGroupStart / ncclSend | ncclRecv x (nranks - 1) / ncclGroupEnd on `stream`, ordered after the render queued there.
  * The handle must be tile-sharded (vf_terrain_set_tile_shard); it sends exactly its local tiles (local_tiles * 16384
  * bytes) from its current output buffer.  On the root `dev_gathered` is [nranks][stride_tiles][64][64][4]: rank r's slab lands in
@@ -244,7 +265,7 @@ int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gat
 int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream);
 
 /* ---- diagnostics: the fragment stage on its own (BASELINE.json north_star names it) ----------------------------
- * Renders the current uniforms once with the visibility store enabled (into scratch buffers: the handle's output, feedback
+ * Renders the frame vf_terrain_render drew last (the current uniforms before the first render) once with the visibility store enabled (into scratch buffers: the handle's output, feedback
  * and timing state stay as they were), then runs `repeats` launches of the resolve kernel -- visibility (H, W) u32 ->
  * RGBA8 through fs_main + sRGB store (src/shaders/terrain.wgsl:69-91), the same device code the tile kernel runs on its
  * LDS tile -- and reports the average launch time (HIP events) and the number of covered pixels.  Whole-frame handles only.

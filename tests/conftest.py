@@ -35,7 +35,7 @@ def _toolchain_present():
 # toolchain (plain CI) they are left out with a note, and the oracle + fixture tests still run; where the toolchain exists a
 # build failure stays a loud error (the HIP extension is the product, there is no fallback to test instead).
 NATIVE_MODULES = ["test_host_api.py", "test_tools_cli.py", "test_cabi_symbols.py", "test_dist_gloo.py", "test_gpu_api.py",
-                  "test_gpu_dem.py", "test_gpu_parity.py", "test_gpu_rccl_loopback.py", "test_gpu_dist_cabi.py", "test_gpu_c5.py"]
+                  "test_gpu_dem.py", "test_gpu_parity.py", "test_gpu_rccl_loopback.py", "test_gpu_dist_cabi.py", "test_gpu_c5.py", "test_gpu_soak.py"]
 HAVE_TOOLCHAIN = _toolchain_present()
 collect_ignore = [] if HAVE_TOOLCHAIN else list(NATIVE_MODULES)
 

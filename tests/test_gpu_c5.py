@@ -24,6 +24,7 @@ def test_c5_orbit_poses_full_size(oracle, luts):
     t = cabi.Terrain(W, H, G, luts["viridis"])
     try:
         t.set_height(h)
+        t.set_shade_precision(0)                                     # EXACT: the poses are compared byte for byte with the oracle
         t.enable_timing(True)
         checked, strips = 0, 0
         for k in range(0, 60):                                       # poses 0..59 in order; every 8th one (from 3) is compared
@@ -55,4 +56,4 @@ def test_bench_c5_workload_runs(tmp_path):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "replicas" and d["n_gpus"] == 1 and d["steps"] == 8 and d["unit"] == "Mpix/s"
     assert d["config"]["grid"] == 2048 and (d["config"]["width"], d["config"]["height"]) == (1920, 1080)
-    assert d["value"] > 0 and d["ms_per_pose"] > 0 and d["roofline"]["bound"] == "valu"
+    assert d["value"] > 0 and d["ms_per_pose"] > 0 and d["roofline"]["bound"] == "hbm"

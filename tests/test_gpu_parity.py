@@ -16,6 +16,8 @@ from conftest import DEFAULT_CAMERA, FILL_CAMERA, GOLDEN, heightmap
 pytestmark = pytest.mark.gpu
 
 RGBA_TOL = 1   # LSB per channel (BASELINE.json north_star: "RGBA within +-1 LSB of reference")
+EXACT, FAST = 0, 1   # vf_terrain_set_shade_precision: EXACT reproduces the oracle bit for bit (0 LSB), FAST (default) stays within RGBA_TOL
+FAST_DIFF = np.zeros(4, np.int64)   # channel values of the FAST frames seen by hip_frame / compare_both: differing from the oracle by 0, 1, 2, >2 LSB
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +27,17 @@ def cabi():
     return C
 
 
-def hip_frame(cabi, u, W, H, G, height, lut, srgb=True, shard=None, shade_mode=0):
+def note_fast(rgba_fast, rgba_exact):
+    """The FAST frame against the EXACT one (= the oracle's, asserted by the caller): never more than RGBA_TOL apart."""
+    d = np.abs(rgba_fast.astype(np.int16) - rgba_exact.astype(np.int16))
+    FAST_DIFF[:] += np.bincount(np.minimum(d, 3).ravel(), minlength=4)
+    assert int(d.max(initial=0)) <= RGBA_TOL, f"fast fragment path differs from the exact one by {int(d.max())} LSB"
+
+
+def hip_frame(cabi, u, W, H, G, height, lut, srgb=True, shard=None, shade_mode=0, frames=1):
+    """One handle, `frames` frames of the default (FAST) precision -- the last of them planned with the feedback of the ones
+    before -- then the same frame with the EXACT arithmetic: returns the EXACT frame and the visibility (the caller holds them
+    against the oracle); the FAST frame must stay within RGBA_TOL of it."""
     t = cabi.Terrain(W, H, G, lut, lut_is_srgb=srgb)
     try:
         t.set_uniforms(u)
@@ -34,21 +46,44 @@ def hip_frame(cabi, u, W, H, G, height, lut, srgb=True, shard=None, shade_mode=0
             t.set_height(height)
         if shard:
             t.set_shard(*shard)
+        for _ in range(frames):
+            t.render()
+        fast = t.read_rgba()
+        vis_fast = t.read_visibility()
+        assert np.array_equal(fast, t.read_rgba())      # read_visibility re-renders: the frame must not change
+        t.set_shade_precision(EXACT)
         t.render()
         rgba = t.read_rgba()
         vis = t.read_visibility()
-        rgba2 = t.read_rgba()            # read_visibility re-renders: the frame must not change
-        assert np.array_equal(rgba, rgba2)
+        assert np.array_equal(rgba, t.read_rgba())
+        assert np.array_equal(vis, vis_fast)            # the precision switch never touches visibility
+        note_fast(fast, rgba)
         return rgba, vis
     finally:
         t.close()
 
 
+def compare_both(t, ref_rgba, ref_vis):
+    """The handle's current frame set-up rendered FAST (as it is) and EXACT against the oracle; leaves the handle FAST."""
+    t.render()
+    fast = t.read_rgba()
+    t.set_shade_precision(EXACT)
+    try:
+        t.render()
+        rgba = t.read_rgba(); vis = t.read_visibility()
+    finally:
+        t.set_shade_precision(FAST)
+    assert_parity(rgba, vis, ref_rgba, ref_vis)
+    note_fast(fast, rgba)
+    return fast
+
+
 def assert_parity(rgba, vis, ref_rgba, ref_vis):
+    """EXACT frame against the oracle: identical visibility; RGBA within the stated tolerance (observed: 0)."""
     assert vis.shape == ref_vis.shape and rgba.shape == ref_rgba.shape
     bad = int((vis != ref_vis).sum())
     assert bad == 0, f"visibility differs at {bad} pixels"
-    d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max()
+    d = np.abs(rgba.astype(np.int16) - ref_rgba.astype(np.int16)).max(initial=0)
     assert d <= RGBA_TOL, f"RGBA differs by {d} LSB"
     return int(d)
 
@@ -155,7 +190,7 @@ def test_random_scenes_fuzz(cabi, oracle, luts, seed):
     u[36] = float(rng.choice([1.0, 1.0, 0.3, 2.5]))                     # spacing
     cmap = str(rng.choice(["viridis", "magma", "terrain"]))
     ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts[cmap], nthreads=8)
-    rgba, vis = hip_frame(cabi, u, W, H, G, h, luts[cmap])
+    rgba, vis = hip_frame(cabi, u, W, H, G, h, luts[cmap], frames=4)      # the compared frames are planned with feedback (strips)
     assert_parity(rgba, vis, ref_rgba, ref_vis)
 
 
@@ -217,7 +252,7 @@ def test_c4_full_size_properties(c4, oracle, cam):
         assert np.array_equal(out, a), (nranks, band)
     # interleaved-tile shards (the bench's N > 1 layout): every rank's tile-major slab, placed by vf_tile_layout
     from vulkan_forge_amd import cabi as _cabi
-    for nranks, skew in ((2, 1), (8, 3), (3, 5)):
+    for nranks, skew in ((2, 1), (8, 3), (3, 5), (2, 0), (4, 0), (8, 0)):     # skew 0 (column stripes) is the bench's default N > 1 layout
         out = np.zeros_like(a)
         for r in range(nranks):
             t.set_tile_shard(r, nranks, skew)
@@ -267,10 +302,8 @@ def test_c4_default_camera_full_oracle_parity(c4, oracle, luts):
     u = oracle.default_uniforms(1, W, H)
     t.set_shard(0, 1, 64)
     t.set_uniforms(u)
-    t.render()
-    rgba = t.read_rgba(); vis = t.read_visibility()
     ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
-    assert_parity(rgba, vis, ref_rgba, ref_vis)
+    compare_both(t, ref_rgba, ref_vis)
 
 
 def test_c4_fill_camera_full_oracle_parity(c4, oracle, luts):
@@ -282,9 +315,8 @@ def test_c4_fill_camera_full_oracle_parity(c4, oracle, luts):
     t.set_uniforms(u)
     for _ in range(4):
         t.render()
-    rgba = t.read_rgba(); vis = t.read_visibility()
     ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
-    assert_parity(rgba, vis, ref_rgba, ref_vis)
+    compare_both(t, ref_rgba, ref_vis)
 
 
 def test_fragment_stage_diagnostics_reproduce_the_frame(c4, oracle):
@@ -299,8 +331,40 @@ def test_fragment_stage_diagnostics_reproduce_the_frame(c4, oracle):
         ft = t.fragment_stage(repeats=3)
         assert ft["equal_to_frame"] == 1 and ft["repeats"] == 3 and ft["resolve_ms"] > 0.0
         assert lo < ft["covered_pixels"] / float(W * H) < hi, ft
-        assert ft["covered_pixels"] == int((a != np.array([39, 39, 48, 255], np.uint8)).any(axis=2).sum()) or True   # (a covered pixel may shade to the clear colour)
+        assert ft["covered_pixels"] >= int((a != np.array([39, 39, 48, 255], np.uint8)).any(axis=2).sum())   # (a covered pixel may shade to the clear colour, never the reverse)
+        assert ft["covered_pixels"] == int((t.read_visibility() != 0).sum())
         assert np.array_equal(t.read_rgba(), a)                         # the caller's frame is untouched
+
+
+def test_visibility_and_fragment_diagnostics_without_a_rendered_frame(cabi, oracle, luts):
+    """vf_terrain_read_visibility / vf_terrain_debug_fragment_stage re-draw a frame into scratch buffers: the frame
+    vf_terrain_render drew last, or -- before any render on this shard layout -- the CURRENT uniforms (never stale or
+    uninitialised ones), any number of times in a row."""
+    W, H, G = 300, 200, 48
+    h = heightmap(31, G)
+    u1 = oracle.default_uniforms(1, W, H)
+    u2 = oracle.look_at_uniforms(1, W, H, (2.0, 2.5, -3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.1, 100.0)
+    (_, v1), (_, v2) = (oracle.render_terrain(u, W, H, G, h, luts["viridis"]) for u in (u1, u2))
+    assert not np.array_equal(v1, v2)
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h); t.set_uniforms(u1)
+        assert np.array_equal(t.read_visibility(), v1)
+        assert np.array_equal(t.read_visibility(), v1)                   # twice, no vf_terrain_render in between
+        t.set_uniforms(u2)
+        assert np.array_equal(t.read_visibility(), v2)                   # still no frame: the current uniforms
+        ft = t.fragment_stage(repeats=1)
+        assert ft["equal_to_frame"] == 1 and ft["covered_pixels"] == int((v2 != 0).sum())
+        with pytest.raises(cabi.VfError):
+            t.read_rgba()                                                # the diagnostics did not count as a rendered frame
+        t.render(); a = t.read_rgba()
+        t.set_uniforms(u1)
+        assert np.array_equal(t.read_visibility(), v2)                   # the frame drawn last, whatever was set since
+        assert np.array_equal(t.read_rgba(), a)
+        t.set_shard(0, 1, 64)                                            # new layout: that frame is forgotten
+        assert np.array_equal(t.read_visibility(), v1)
+    finally:
+        t.close()
 
 
 def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
@@ -316,6 +380,7 @@ def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
     t = cabi.Terrain(W, H, G, luts["viridis"])
     try:
         t.set_height(h)
+        t.set_shade_precision(EXACT)                                    # compared byte for byte with the oracle below
         t.enable_timing(True)
         strips_seen = 0
         for k in (0, 0, 0, 1, 0, 1, 1, 1, 0):
@@ -341,6 +406,7 @@ def test_orbiting_camera_back_to_back(cabi, oracle, luts):
     t = cabi.Terrain(W, H, G, luts["viridis"])
     try:
         t.set_height(h)
+        t.set_shade_precision(EXACT)
         for nposes, frames in ((48, 9), (720, 12)):                       # 7.5 degrees per frame, then 0.5
             eyes = [(4.2 * math.cos(2 * math.pi * k / nposes), 2.0, 4.2 * math.sin(2 * math.pi * k / nposes)) for k in range(frames)]
             us = [oracle.look_at_uniforms(1, W, H, e, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0, 0.1, 100.0) for e in eyes]
@@ -363,9 +429,12 @@ def test_maximum_grid_8192(cabi, oracle, luts):
     t = cabi.Terrain(W, H, G, luts["viridis"])
     try:
         t.set_height(h); t.set_uniforms(u)
+        t.render(); fast = t.read_rgba()
+        t.set_shade_precision(EXACT)
         t.render(); a = t.read_rgba()
         ref, _ = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()), want_vis=False)
         assert np.array_equal(a, ref)
+        note_fast(fast, a)
         out = np.zeros_like(a)
         for r in range(3):
             t.set_tile_shard(r, 3, 5); t.render()
@@ -389,10 +458,9 @@ def test_c5_pose_batch_subset(cabi, oracle, luts):
             th = 2 * math.pi * k / 64
             cam = ((3 * math.sqrt(2) * math.cos(th), 2.0, 3 * math.sqrt(2) * math.sin(th)), (0, 0, 0), (0, 1, 0), 45.0, 0.1, 100.0)
             u = oracle.look_at_uniforms(1, W, H, *cam)
-            t.set_uniforms(u); t.render()
-            rgba = t.read_rgba(); vis = t.read_visibility()
+            t.set_uniforms(u)
             ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=8)
-            assert_parity(rgba, vis, ref_rgba, ref_vis)
+            compare_both(t, ref_rgba, ref_vis)
     finally:
         t.close()
 
@@ -406,9 +474,9 @@ def test_height_reupload_and_resize(cabi, oracle, luts):
         t.set_uniforms(u)
         for shape in ((2, 2), (40, 40), (40, 40), (13, 61), (1, 1)):
             h = heightmap(sum(shape), shape[0], shape[1])
-            t.set_height(h); t.render()
+            t.set_height(h)
             ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["magma"])
-            assert_parity(t.read_rgba(), t.read_visibility(), ref_rgba, ref_vis)
+            compare_both(t, ref_rgba, ref_vis)
     finally:
         t.close()
 
@@ -428,7 +496,7 @@ h = np.random.default_rng(9).random((64, 64), dtype=np.float32) * np.float32(0.5
 d_h = torch.from_numpy(h).cuda()
 gathered = torch.zeros((nr, H // nr, W, 4), dtype=torch.uint8, device="cuda")
 t = cabi.Terrain(W, H, G, lut)
-t.set_uniforms(u)
+t.set_uniforms(u); t.set_shade_precision(0)                 # EXACT: compared byte for byte with the oracle
 t.set_height_device(d_h.data_ptr(), 64, 64)                 # borrowed texture already in HBM
 stream = torch.cuda.current_stream().cuda_stream
 for r in range(nr):
@@ -449,7 +517,7 @@ u = oracle.default_uniforms(1, W, H)
 ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
 for nr, skew in ((3, 5), (2, 1), (5, 3)):
     t = cabi.Terrain(W, H, G, lut)
-    t.set_uniforms(u); t.set_height_device(d_h.data_ptr(), 64, 64)
+    t.set_uniforms(u); t.set_height_device(d_h.data_ptr(), 64, 64); t.set_shade_precision(0)
     stride = max(len(cabi.tile_layout(W, H, r, nr, skew, lib=t.lib)) for r in range(nr)) + 1     # a stride larger than needed is fine
     gathered = torch.zeros((nr, stride * 4096), dtype=torch.int32, device="cuda")
     for r in range(nr):
@@ -503,3 +571,13 @@ def test_triangle_path(oracle, W, H):
     assert np.array_equal(a, oracle.render_triangle(W, H))
     if (W, H) == (33, 21):
         assert np.array_equal(a, Z["triangle_33x21/rgba"])
+
+
+def test_zz_fast_precision_histogram():
+    """Runs last in this module: what the default (FAST) fragment path did across every frame the tests above rendered with both
+    precisions -- never more than 1 LSB from the EXACT one (asserted per frame), and equal nearly everywhere."""
+    total = int(FAST_DIFF.sum())
+    assert total > 0
+    print(f"\nFAST vs EXACT over {total} channel values: 0 LSB {FAST_DIFF[0]}, 1 LSB {FAST_DIFF[1]} ({100.0 * FAST_DIFF[1] / total:.4f} %), 2 LSB {FAST_DIFF[2]}, more {FAST_DIFF[3]}")
+    assert FAST_DIFF[2] == 0 and FAST_DIFF[3] == 0
+    assert FAST_DIFF[1] <= 0.01 * total

@@ -18,10 +18,10 @@ VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -
 SYMBOLS = [
     "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
-    "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
+    "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
-    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
+    "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_frame_times", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
     "vf_dist_available", "vf_dist_unique_id", "vf_dist_comm_init", "vf_dist_comm_destroy", "vf_dist_gather_tiles", "vf_dist_gather_bands",
     "vf_terrain_debug_fragment_stage",
@@ -60,6 +60,7 @@ _PROTOS = {
     "vf_terrain_set_height": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_set_height_device": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_set_shade_mode": (_i, [_vp, _i]),
+    "vf_terrain_set_shade_precision": (_i, [_vp, _i]),
     "vf_terrain_set_shard": (_i, [_vp, _u32, _u32, _u32]),
     "vf_terrain_local_rows": (_i, [_vp, C.POINTER(_u32)]),
     "vf_terrain_set_tile_shard": (_i, [_vp, _u32, _u32, _u32]),
@@ -75,6 +76,7 @@ _PROTOS = {
     "vf_terrain_read_visibility": (_i, [_vp, _vp]),
     "vf_terrain_enable_timing": (_i, [_vp, _i]),
     "vf_terrain_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "vf_terrain_frame_times": (_i, [_vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_item_stats": (_i, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_phase_cycles": (_i, [_vp, _vp, _u32]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
@@ -173,6 +175,11 @@ class Terrain:
     def set_shade_mode(self, mode):
         """0 = REFERENCE (terrain.wgsl as coded), 1 = SPEC_T32 (documented-only stage; oracle-validated)."""
         self._check(self.lib.vf_terrain_set_shade_mode(self.t, int(mode)))
+
+    def set_shade_precision(self, precision):
+        """0 = EXACT (IEEE binary32 in a fixed order: the oracle bit for bit), 1 = FAST (default; hardware rcp / rsq / sin / cos /
+        log / exp, within 1 LSB of EXACT, visibility identical)."""
+        self._check(self.lib.vf_terrain_set_shade_precision(self.t, int(precision)))
 
     def set_shard(self, rank, nranks, band_h=64):
         self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))
@@ -287,6 +294,12 @@ class Terrain:
         out = np.zeros(32, np.uint64)
         self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 32))
         return out
+
+    def frame_times(self):
+        """(tile_ms, period_ms) per timed frame, oldest first (at most the last 64); period_ms[0] is 0."""
+        tile, period, n = np.zeros(64, np.float32), np.zeros(64, np.float32), _u32(0)
+        self._check(self.lib.vf_terrain_frame_times(self.t, tile.ctypes.data, period.ctypes.data, 64, C.byref(n)))
+        return tile[:n.value].copy(), period[:n.value].copy()
 
     def timings(self):
         tm = Timings()

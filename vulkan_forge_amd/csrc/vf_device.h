@@ -64,6 +64,8 @@ struct FrameParams {
     uint32_t clear_rgba;            // packed sRGB8 clear colour
     uint32_t shade_mode;            // 0 REFERENCE (terrain.wgsl as coded), 1 SPEC_T32 (the documented fragment stage)
     const float *tex;               // height texture (SPEC_T32 normals)
+    float inv2hr;                   // 1 / (2 h_range): the fast fragment path multiplies where terrain.wgsl:71 divides
+    uint32_t div_m, div_s;          // cell / nm1 == mulhi(cell, div_m) >> div_s for every cell < 2^26 (host: cell_divider)
 };
 
 // inclusive pixel rectangle (clamped to the target) a grid block, or a whole block row, may touch; x0 > x1 = empty

@@ -87,8 +87,9 @@ struct vf_terrain {
     // uniforms
     float u[44];
     bool have_uniforms = false;
-    float u_frame[44];                   // uniforms / shade mode of the frame vf_terrain_render drew last (visibility, fragment diagnostics)
+    float u_frame[44] = {};              // uniforms / shade mode of the frame vf_terrain_render drew last (visibility, fragment diagnostics)
     uint32_t shade_mode_frame = 0;
+    bool have_frame = false;             // u_frame is valid: set by vf_terrain_render only, cleared when the shard layout changes
     uint32_t *d_rgba_scratch = nullptr;  // output of those diagnostic re-renders: the caller's frame is never overwritten
     uint32_t *d_diag = nullptr;          // [0] covered pixels (fragment-stage diagnostics)
     float u_drawn[32];                   // view + proj of the frame rendered last (is the camera moving?)
@@ -119,6 +120,7 @@ struct vf_terrain {
         uint32_t *work_count = nullptr;  // [0] work items, [1] split budget used, [2] queue head, [3] items handed to the complete tile kernel
         uint32_t *redo = nullptr;        // those items (indices into work)
         uint32_t *background = nullptr;  // per local tile: bit 0 = no block row reaches it; bits 8.. = log2 of the strips it is cut into
+        uint32_t *flags_new = nullptr;   // the same words as k_plan writes them; k_plan_sort moves them into `background`
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
                                          // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
@@ -135,6 +137,7 @@ struct vf_terrain {
     uint32_t *d_merge = nullptr;         // where the depth slices of a heavy tile meet: [tiles][16] arrival counters, then [tiles][64 x 64] ids; zero between frames
     bool shard_tiles = false;
     uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
+    uint32_t precision = VF_PRECISION_FAST, precision_frame = VF_PRECISION_FAST;   // fragment arithmetic (of the frame vf_terrain_render drew last)
     uint32_t local_tiles = 0;            // tiles this handle renders (= ntx * local tile rows unless tile-sharded)
     uint32_t *d_rgba = nullptr;
     uint32_t *d_vis = nullptr;           // only allocated for vf_terrain_read_visibility
@@ -280,10 +283,14 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     t->local_tiles = t->ntx * t->nty;
     std::memset(t->u, 0, sizeof t->u);
 
-    float lut[768];
-    for (int i = 0; i < 256; ++i)
+    // linear LUT as the kernels stage it: 257 x {r, g, b, 0}, entry 256 = entry 255
+    float lut[kLutFloats];
+    for (int i = 0; i <= 256; ++i) {
+        const int k = i < 256 ? i : 255;
         for (int ch = 0; ch < 3; ++ch)
-            lut[3 * i + ch] = lut_is_srgb ? tables().decode[lut_rgba8[4 * i + ch]] : (float)lut_rgba8[4 * i + ch] / 255.0f;
+            lut[kLutStride * i + ch] = lut_is_srgb ? tables().decode[lut_rgba8[4 * k + ch]] : (float)lut_rgba8[4 * k + ch] / 255.0f;
+        lut[kLutStride * i + 3] = 0.0f;
+    }
     const float zero = 0.0f;
 
     hipError_t err = hipSuccess;
@@ -313,6 +320,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         A((void **)&S.work_count, 4 * sizeof(uint32_t));
         A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
         A((void **)&S.background, all_tiles * sizeof(uint32_t));
+        A((void **)&S.flags_new, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles * 65 + 1) * sizeof(uint32_t));
         if (err == hipSuccess) err = hipMemset(S.background, 0, all_tiles * sizeof(uint32_t));
         if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
@@ -358,7 +366,7 @@ void vf_terrain_destroy(vf_terrain *t)
     void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_merge, t->d_rgba_scratch, t->d_diag };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
-        void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.feedback };
+        void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.flags_new, S.feedback };
         for (void *p : sp) if (p) (void)hipFree(p);
         if (S.planned) (void)hipEventDestroy(S.planned);
         if (S.drawn) (void)hipEventDestroy(S.drawn);
@@ -439,6 +447,14 @@ int vf_terrain_set_shade_mode(vf_terrain *t, int mode)
     return VF_OK;
 }
 
+int vf_terrain_set_shade_precision(vf_terrain *t, int precision)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (precision != VF_PRECISION_EXACT && precision != VF_PRECISION_FAST) return fail(VF_ERR_INVALID, "unknown shade precision");
+    t->precision = (uint32_t)precision;
+    return VF_OK;
+}
+
 int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
@@ -450,7 +466,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->shard_tiles = false;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
     t->local_tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
-    t->rendered = false;
+    t->rendered = false; t->have_frame = false;
     t->frames_since_reset = 0;
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
@@ -493,7 +509,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->shard_tiles = true; t->local_tiles = n;
     t->rank = rank; t->nranks = nranks; t->skew = skew;
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
-    t->rendered = false;
+    t->rendered = false; t->have_frame = false;
     t->frames_since_reset = 0;
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
@@ -566,6 +582,16 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.local_rows = t->local_rows;
     P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = t->skew;
     P.shade_mode = t->shade_mode; P.tex = t->d_height;
+    P.inv2hr = 1.0f / (2.0f * P.h_range);
+    {   // cell / nm1 as mulhi(cell, m) >> s, exact for cell < 2^26 (nm1 < 2^13): s = 31 + ceil(log2 nm1) - 32, m = ceil(2^(s + 32) / nm1)
+        const uint32_t d = P.nm1;
+        if (d <= 1u) { P.div_m = 0u; P.div_s = 0u; }       // one cell: row 0
+        else {
+            const uint32_t L = ilog2(d);                   // ceil(log2 d)
+            P.div_s = L - 1u;
+            P.div_m = (uint32_t)((((uint64_t)1 << (31u + L)) + d - 1u) / d);
+        }
+    }
     const SrgbTables &T = tables();
     P.clear_rgba = T.encode(0.02f) | (T.encode(0.02f) << 8) | (T.encode(0.03f) << 16) | 0xFF000000u;   // src/terrain/mod.rs:421
 }
@@ -593,6 +619,9 @@ static float camera_shift_px(const vf_terrain *t, const float *a, const float *b
     return worst;
 }
 constexpr float kFreshFeedbackPx = 24.0f;   // from here on (3/8 of a tile per frame) the plan waits for the previous frame's feedback
+
+// the fast fragment path exists for fs_main as coded; the documented-only SPEC_T32 stage always takes the exact arithmetic
+static bool fast_shading(const vf_terrain *t) { return t->precision == VF_PRECISION_FAST && t->shade_mode == VF_SHADE_REFERENCE; }
 
 static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 {
@@ -658,9 +687,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
             hipLaunchKernelGGL(k_quantum, dim3(1), dim3(512), 0, side, O.feedback, t->ntx * t->nty, quantum);
         }
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
-        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.background, S.work, S.work_count,
+        hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.flags_new, S.work, S.work_count,
                            F.feedback, quantum, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
-        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty);
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty,
+                           S.flags_new, S.background, ntiles);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));
@@ -683,12 +713,19 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
-        if (write_vis) {
-            hipLaunchKernelGGL((k_tile<true, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<true, true>), few, threads, 0, s, VF_TILE_ARGS);
+        const bool fast = fast_shading(t);
+        if (write_vis && fast) {
+            hipLaunchKernelGGL((k_tile<true, false, true>), per_cu, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<true, true, true>), few, threads, 0, s, VF_TILE_ARGS);
+        } else if (write_vis) {
+            hipLaunchKernelGGL((k_tile<true, false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<true, true, false>), few, threads, 0, s, VF_TILE_ARGS);
+        } else if (fast) {
+            hipLaunchKernelGGL((k_tile<false, false, true>), per_cu, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<false, true, true>), few, threads, 0, s, VF_TILE_ARGS);
         } else {
-            hipLaunchKernelGGL((k_tile<false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<false, true>), few, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<false, false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
+            hipLaunchKernelGGL((k_tile<false, true, false>), few, threads, 0, s, VF_TILE_ARGS);
         }
 #undef VF_TILE_ARGS
     }
@@ -707,7 +744,8 @@ int vf_terrain_render(vf_terrain *t, void *stream)
     if (!t->have_uniforms) return fail(VF_ERR_INVALID, "uniforms not set");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     std::memcpy(t->u_frame, t->u, sizeof t->u_frame);
-    t->shade_mode_frame = t->shade_mode;
+    t->shade_mode_frame = t->shade_mode; t->precision_frame = t->precision;
+    t->have_frame = true;
     return render_impl(t, stream ? (hipStream_t)stream : t->ctx->stream, false);
 }
 
@@ -729,14 +767,16 @@ static int render_visibility(vf_terrain *t)
     uint32_t *const out_now = t->d_rgba;
     const hipStream_t stream_now = t->last_stream;
     const bool timing = t->timing, have_drawn = t->have_drawn, moving = t->camera_moving, was_moving = t->was_moving;
-    const uint32_t mode_now = t->shade_mode, since = t->frames_since_reset;
-    if (t->rendered) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; }
+    const uint32_t mode_now = t->shade_mode, prec_now = t->precision, since = t->frames_since_reset;
+    const bool rendered = t->rendered;
+    if (t->have_frame) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; t->precision = t->precision_frame; }
     t->d_rgba = t->d_rgba_scratch; t->timing = false;
     rc = render_impl(t, t->ctx->stream, true);
     hipError_t e = hipStreamSynchronize(t->ctx->stream);
     std::memcpy(t->u, u_now, sizeof u_now); std::memcpy(t->u_drawn, u_drawn, sizeof u_drawn);
     t->d_rgba = out_now; t->last_stream = stream_now; t->timing = timing; t->have_drawn = have_drawn;
-    t->camera_moving = moving; t->was_moving = was_moving; t->shade_mode = mode_now; t->frames_since_reset = since;
+    t->camera_moving = moving; t->was_moving = was_moving; t->shade_mode = mode_now; t->precision = prec_now; t->frames_since_reset = since;
+    t->rendered = rendered;                                 // the diagnostic frame went to scratch buffers: the caller's output is as it was
     if (rc != VF_OK) return rc;
     if (e != hipSuccess) return fail(VF_ERR_HIP, std::string("visibility render: ") + hipGetErrorString(e));
     return VF_OK;
@@ -872,21 +912,34 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
     FrameParams P;
     float u_now[44];
     std::memcpy(u_now, t->u, sizeof u_now);
-    const uint32_t mode_now = t->shade_mode;
-    if (t->rendered) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; }
+    const uint32_t mode_now = t->shade_mode, prec_now = t->precision;
+    if (t->have_frame) { std::memcpy(t->u, t->u_frame, sizeof t->u); t->shade_mode = t->shade_mode_frame; t->precision = t->precision_frame; }
     build_params(t, P);
-    std::memcpy(t->u, u_now, sizeof u_now); t->shade_mode = mode_now;
+    const bool fast = fast_shading(t);
+    std::memcpy(t->u, u_now, sizeof u_now); t->shade_mode = mode_now; t->precision = prec_now;
     hipStream_t s = t->ctx->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (err == hipSuccess) err = hipEventCreate(&e0);
     if (err == hipSuccess) err = hipEventCreate(&e1);
-    const uint32_t per_cu = 8;                                          // resident 256-thread workgroups per CU (persistent, grid stride)
-    const dim3 grid(std::min<uint32_t>(((t->W + 255u) / 256u) * t->H, (uint32_t)std::max(1, t->ctx->prop.multiProcessorCount) * per_cu)), threads(256);
+    // 16-byte HBM accesses when the rows allow them and the frame holds no clipped primitive (VF_RESOLVE_PER_PIXEL=1: the per-pixel form)
+    const bool quads = !redo && t->W % 4u == 0 && !std::getenv("VF_RESOLVE_PER_PIXEL");
+    // Persistent workgroups, a multiple of 8 of them (one share per XCD).  FEW per CU on purpose: the record gathers of more waves
+    // than these evict each other's lines from the 32 KB L1 (C4 fill camera, k_resolve4: 3 per CU 0.130 ms, 4: 0.144, 8: 0.148)
+    const uint32_t per_cu = std::getenv("VF_RESOLVE_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("VF_RESOLVE_PER_CU"))) : (quads ? 3u : 4u);
+    const uint32_t cus = (uint32_t)std::max(8, t->ctx->prop.multiProcessorCount) / 8u * 8u;
+    const dim3 grid(std::min<uint32_t>((((t->W + 31u) / 32u) * ((t->H + 7u) / 8u) + 7u) / 8u * 8u, cus * per_cu)), threads(256);   // 32 x 8 pixel regions
     const vf_terrain::PlanState &S = t->ps[(t->frame_no - 1u) & 1u];     // the set-up of the frame just rendered
     const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
+    // four pixels per lane when the rows allow 16-byte accesses and the frame holds no clipped primitive (VF_RESOLVE_PER_PIXEL=1: the per-pixel form)
+    constexpr uint32_t RQ = 8u, RY = 32u;                  // k_resolve4's region: 8 quads x 32 rows
+    const dim3 grid4(std::min<uint32_t>((((t->W / 4u + RQ - 1u) / RQ) * ((t->H + RY - 1u) / RY) + 7u) / 8u * 8u, cus * per_cu));
     auto launch = [&](uint32_t *covered) {
-        if (redo) hipLaunchKernelGGL((k_resolve<true>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
-        else hipLaunchKernelGGL((k_resolve<false>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+        if (quads && fast) hipLaunchKernelGGL((k_resolve4<true>), grid4, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, (const uint4 *)t->d_vis, (uint4 *)d_out, covered);
+        else if (quads) hipLaunchKernelGGL((k_resolve4<false>), grid4, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, (const uint4 *)t->d_vis, (uint4 *)d_out, covered);
+        else if (redo && fast) hipLaunchKernelGGL((k_resolve<true, true>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+        else if (redo) hipLaunchKernelGGL((k_resolve<true, false>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+        else if (fast) hipLaunchKernelGGL((k_resolve<false, true>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
+        else hipLaunchKernelGGL((k_resolve<false, false>), grid, threads, 0, s, P, V, t->d_lut, t->ctx->d_thresh, t->d_vis, d_out, covered);
     };
     if (err == hipSuccess) err = hipMemsetAsync(t->d_diag, 0, 4 * sizeof(uint32_t), s);
     if (err == hipSuccess) { launch(t->d_diag); err = hipGetLastError(); }       // warm-up launch, counts the covered pixels
@@ -992,6 +1045,28 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
         for (uint32_t w : bits) n += (uint32_t)__builtin_popcount(w);
         out->blocks_distinct = n;
     }
+    return VF_OK;
+}
+
+int vf_terrain_frame_times(vf_terrain *t, float *tile_ms, float *period_ms, uint32_t max_frames, uint32_t *count)
+{
+    if (!t || !count) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->timing || !t->rendered || t->timed_frames == 0) return fail(VF_ERR_INVALID, "timing not enabled or nothing rendered");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    const uint32_t ring = (uint32_t)vf_terrain::kTimingRing;
+    const uint32_t nf = std::min(std::min(t->timed_frames, ring), max_frames);
+    const uint32_t first = t->timed_frames - nf;            // frame numbers first .. timed_frames - 1 live in ring slot (number % ring)
+    for (uint32_t k = 0; k < nf; ++k) {
+        hipEvent_t *e = t->ev[(first + k) % ring];
+        VF_HIP_TRY(hipEventSynchronize(e[3]));
+        if (tile_ms) VF_HIP_TRY(hipEventElapsedTime(&tile_ms[k], e[4], e[3]));
+        if (period_ms) {
+            period_ms[k] = 0.0f;
+            if (k) VF_HIP_TRY(hipEventElapsedTime(&period_ms[k], t->ev[(first + k - 1u) % ring][3], e[3]));
+        }
+    }
+    *count = nf;
     return VF_OK;
 }
 
@@ -1317,6 +1392,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;   // (optional)
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1340,6 +1416,7 @@ const Rccl &resolve_rccl()
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
         x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
         x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(sym("ncclCommUserRank"));
+        x.CommCuDevice = reinterpret_cast<decltype(x.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
         x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
         x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
@@ -1405,7 +1482,10 @@ int vf_dist_comm_init(vf_ctx *ctx, const uint8_t id[VF_DIST_UNIQUE_ID_BYTES], in
 void vf_dist_comm_destroy(void *comm)
 {
     const Rccl &R = resolve_rccl();
-    if (R.ok && comm) (void)R.CommDestroy((ncclComm_t)comm);
+    if (!R.ok || !comm) return;
+    int dev = -1;                                           // the communicator's own device, whatever the calling thread has current
+    if (R.CommCuDevice && R.CommCuDevice((ncclComm_t)comm, &dev) == ncclSuccess && dev >= 0) (void)hipSetDevice(dev);
+    (void)R.CommDestroy((ncclComm_t)comm);
 }
 
 int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gathered, uint32_t stride_tiles, void *stream)
@@ -1424,15 +1504,17 @@ int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gat
     }
     const size_t tile_bytes = (size_t)kTileW * kTileH * 4;
     const bool is_root = (uint32_t)root == t->rank;
-    if (is_root) {
-        if (!dev_gathered) return fail(VF_ERR_INVALID, "the root needs the gather buffer");
-        for (uint32_t r = 0; r < t->nranks; ++r) {
-            uint32_t n = 0;
-            rc = vf_tile_layout(t->W, t->H, r, t->nranks, t->skew, nullptr, 0, &n);
-            if (rc != VF_OK) return rc;
-            if (n > stride_tiles) return fail(VF_ERR_INVALID, "stride_tiles is smaller than the largest shard");
-        }
+    // Checked on EVERY rank, from what every rank can compute locally, before anything is posted: a rank that returned here
+    // while the others had queued their ncclSend would leave them waiting for a receive that never comes.  (The one check only
+    // the root can make -- its gather buffer -- must hold by construction: a root that passes NULL fails alone and the senders
+    // hang; vf_hip.h says so.)
+    for (uint32_t r = 0; r < t->nranks; ++r) {
+        uint32_t n = 0;
+        rc = vf_tile_layout(t->W, t->H, r, t->nranks, t->skew, nullptr, 0, &n);
+        if (rc != VF_OK) return rc;
+        if (n > stride_tiles) return fail(VF_ERR_INVALID, "stride_tiles is smaller than the largest shard");
     }
+    if (is_root && !dev_gathered) return fail(VF_ERR_INVALID, "the root needs the gather buffer");
     uint8_t *const slots = (uint8_t *)dev_gathered;
     uint8_t *const own_slot = is_root ? slots + (size_t)root * stride_tiles * tile_bytes : nullptr;
     const bool in_place = is_root && (uint8_t *)t->d_rgba == own_slot;
@@ -1470,20 +1552,29 @@ int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_ima
     if (is_root && !dev_image) return fail(VF_ERR_INVALID, "the root needs the image buffer");
     const size_t row_bytes = (size_t)t->W * 4;
     std::vector<uint32_t> local(t->nranks, 0u);             // rows a rank has stored so far, band by band
+    // the root's own bands first, as plain device copies on the stream: nothing but RCCL calls inside the group
+    if (is_root) {
+        uint32_t ly0 = 0;
+        for (uint32_t b = t->rank; b * t->band_h < t->H; b += t->nranks) {
+            const uint32_t y0 = b * t->band_h, rows = std::min(t->band_h, t->H - y0);
+            uint8_t *dst = (uint8_t *)dev_image + (size_t)y0 * row_bytes;
+            const uint8_t *src = (const uint8_t *)t->d_rgba + (size_t)ly0 * row_bytes;
+            if ((const uint8_t *)dst != src) VF_HIP_TRY(hipMemcpyAsync(dst, src, rows * row_bytes, hipMemcpyDeviceToDevice, s));
+            ly0 += rows;
+        }
+    }
     VF_RCCL_TRY(R, R.GroupStart());
     ncclResult_t res = ncclSuccess;
-    hipError_t herr = hipSuccess;
-    for (uint32_t b = 0; b * t->band_h < t->H && res == ncclSuccess && herr == hipSuccess; ++b) {
+    for (uint32_t b = 0; b * t->band_h < t->H && res == ncclSuccess; ++b) {
         const uint32_t y0 = b * t->band_h, rows = std::min(t->band_h, t->H - y0), owner = b % t->nranks, ly0 = local[owner];
         local[owner] += rows;
         uint8_t *dst = is_root ? (uint8_t *)dev_image + (size_t)y0 * row_bytes : nullptr;
         const uint8_t *src = (const uint8_t *)t->d_rgba + (size_t)ly0 * row_bytes;
-        if (owner == t->rank && is_root) { if ((const uint8_t *)dst != src) herr = hipMemcpyAsync(dst, src, rows * row_bytes, hipMemcpyDeviceToDevice, s); }
+        if (owner == t->rank && is_root) continue;          // copied above
         else if (is_root) res = R.Recv(dst, rows * row_bytes, ncclUint8, (int)owner, comm, s);
         else if (owner == t->rank) res = R.Send(src, rows * row_bytes, ncclUint8, root, comm, s);
     }
     const ncclResult_t end = R.GroupEnd();
-    if (herr != hipSuccess) return fail(VF_ERR_HIP, std::string("band copy: ") + hipGetErrorString(herr));
     if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
     if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
     return VF_OK;

@@ -247,7 +247,12 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
     __syncthreads();
     for (uint32_t tc = threadIdx.x; tc < P.ntx; tc += blockDim.x) { rc_lo[tc * P.nb + by] = s_lo[tc]; rc_hi[tc * P.nb + by] = s_hi[tc]; }   // [tile column][block row]: a tile reads its column's rows contiguously
     for (uint32_t k = threadIdx.x; k < (P.nb + 15u) / 16u; k += blockDim.x)
-        if (s_seg[k]) seg_list[atomicAdd(seg_count, 1u)] = by | (k << 16);      // (order is irrelevant; the counter is zeroed by the frame's k_clear)
+        if (s_seg[k]) {                                    // (order is irrelevant; the counter is zeroed by the frame's k_clear)
+            // clamped: a frame that failed between this kernel and its k_clear leaves the counter where it was, and the next use of
+            // this plan state must not append past the list (the counter itself sits right behind it)
+            const uint32_t at = atomicAdd(seg_count, 1u);
+            if (at < P.nb * ((P.nb + 15u) / 16u)) seg_list[at] = by | (k << 16);
+        }
     if (threadIdx.x == 0) {
         PixelBox rr;
         if (s_rr[2] < 0) { rr.x0 = 1; rr.y0 = 1; rr.x1 = 0; rr.y1 = 0; }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, co
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     // the segments k_block_boxes listed: those with a block that can reach this shard's part of the target
-    const uint32_t nseg = *seg_count;
+    const uint32_t nseg = min(*seg_count, P.nb * ((P.nb + (uint32_t)kSegBlocks - 1u) / (uint32_t)kSegBlocks));
     for (uint32_t item = blockIdx.x; item < nseg; item += gridDim.x) {
     const uint32_t code = seg_list[item];
     const uint32_t by = code & 0xFFFFu, bx0 = (code >> 16) * kSegBlocks;
@@ -601,7 +606,11 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
 }
 
 // ---- fragment stage ---------------------------------------------------------------------------
-struct ShadeTables { const float *lut; const float *thresh; };   // LDS: 256*3 linear LUT, 256 sRGB thresholds
+// LDS: the linear LUT as 257 x {r, g, b, -} (entry 256 repeats entry 255: the fast path reads texel i and i + 1 as two 16-byte words
+// without a clamp), 256 sRGB thresholds.  (Kept this small on purpose: the tile kernel's LDS has to stay below half a CU's 160 KB
+// or its register budget -- VF_TILE_MIN_WAVES -- is silently dropped.)
+constexpr int kLutStride = 4, kLutFloats = 257 * kLutStride;
+struct ShadeTables { const float *lut; const float *thresh; };
 
 // fs_main (terrain.wgsl:69-91) + Rgba8UnormSrgb store
 __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const ShadeTables &S, const float attr[3])
@@ -644,13 +653,52 @@ __device__ __forceinline__ uint32_t fragment_shader(const FrameParams &P, const 
     uint32_t out = 0xFF000000u;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float l0 = S.lut[i0 * 3 + ch], l1 = S.lut[i1 * 3 + ch];
+        float l0 = S.lut[i0 * kLutStride + ch], l1 = S.lut[i1 * kLutStride + ch];
         float lc = fmaf(f, l1 - l0, l0);
         float v = lc * P.exposure * shade;
         if (P.shade_mode != 0u) v = v / (1.0f + v);          // Reinhard (tests/test_tonemap.py:7-8), before the sRGB store
         out |= srgb_encode(v, S.thresh) << (8 * ch);
     }
     return out;
+}
+
+// ---- the fast fragment path (vf_terrain_set_shade_precision(VF_PRECISION_FAST), the default) -------------------------------
+// The same formulas (terrain.wgsl:69-91 and the interpolation conventions of DESIGN.md section 4) evaluated the way the hardware
+// likes them: v_rcp / v_rsq / v_sin / v_cos / v_log / v_exp (1 ulp) instead of IEEE division, 1/sqrt, the Cody-Waite polynomials and the
+// threshold search; fused multiply-adds; one division for the three barycentrics and the perspective sum together.  Visibility is not
+// touched by any of this; colours stay within 1 LSB of the exact path (BASELINE.json: "RGBA within +-1 LSB"), and nearly always equal:
+// every quantity below is continuous in its inputs and carries a relative error of a few 2^-23, against 2^-8 between two bytes.
+// (The sRGB byte is round(255 oetf(c)) from the hardware log/exp estimate WITHOUT the exact path's fix-up against the threshold table.)
+// Every fused multiply-add below is written out (the file is compiled with -ffp-contract=off): the compiler may not fuse or
+// split anything on its own, so all instantiations -- tile kernel variants, strips, the resolve kernels -- give the same bits.
+__device__ __forceinline__ uint32_t srgb_encode_fast(float c)
+{
+    const float cc = __builtin_amdgcn_fmed3f(c, 0.0f, 1.0f);
+    const float nl = fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(cc) * (1.0f / 2.4f)), -0.055f);
+    const float est = cc <= 0.0031308f ? 12.92f * cc : nl;
+    return (uint32_t)fmaf(est, 255.0f, 0.5f);                          // est in [0, 1]: the conversion truncates, 255.5 -> 255
+}
+__device__ __forceinline__ uint32_t fragment_shader_fast(const FrameParams &P, const ShadeTables &S, float height, float x, float z)
+{
+    const float t = __builtin_amdgcn_fmed3f(fmaf(height, P.inv2hr, 0.5f), 0.0f, 1.0f);
+    const float c = fmaxf(fmaf(t, 256.0f, -0.5f), 0.0f);              // (below 0 both texels are entry 0: the same colour as c = 0)
+    const float i0f = floorf(c);
+    const float f = c - i0f;
+    const uint32_t i0 = (uint32_t)i0f;                                  // 0..255
+    const float4 l0 = *reinterpret_cast<const float4 *>(S.lut + i0 * kLutStride);
+    const float4 l1 = *reinterpret_cast<const float4 *>(S.lut + i0 * kLutStride + kLutStride);
+    // v_sin_f32 / v_cos_f32 take revolutions
+    const float dhdx = 0.325f * __builtin_amdgcn_cosf(x * (1.3f * 0.15915494309189535f));       // 1.3 cos(1.3 x) / 4
+    const float dhdz = -0.275f * __builtin_amdgcn_sinf(z * (1.1f * 0.15915494309189535f));      // -1.1 sin(1.1 z) / 4
+    const float inv = __builtin_amdgcn_rsqf(fmaf(dhdz, dhdz, fmaf(dhdx, dhdx, 1.0f)));
+    // n = (-dhdx, 1, -dhdz) inv;  n . L
+    const float ndl = inv * fmaf(-dhdz, P.Lz, fmaf(-dhdx, P.Lx, P.Ly));
+    const float lambert = __builtin_amdgcn_fmed3f(ndl, 0.0f, 1.0f);
+    const float es = P.exposure * fmaf(lambert, 0.85f, 0.15f);       // 0.15 (1 - l) + l
+    const uint32_t r = srgb_encode_fast(fmaf(f, l1.x - l0.x, l0.x) * es);
+    const uint32_t g = srgb_encode_fast(fmaf(f, l1.y - l0.y, l0.y) * es);
+    const uint32_t b = srgb_encode_fast(fmaf(f, l1.z - l0.z, l0.z) * es);
+    return 0xFF000000u | r | (g << 8) | (b << 16);
 }
 
 __device__ __noinline__ bool clipped_attributes(const GVert v[3], float hw, float hh, uint32_t W, uint32_t H, int32_t px, int32_t py,
@@ -707,14 +755,45 @@ __device__ __forceinline__ uint32_t shade_from_records(const FrameParams &P, con
     return fragment_shader(P, S, attr);
 }
 
+// The fast path's version: the three edge weights from the vertices relative to the pixel centre.  a, b, c = v0, v1, v2 - P are
+// integers below 2^24 in magnitude (the fast raster path only takes primitives less than 2^24 across, and P lies inside the bounding
+// box), so they convert exactly; e0 = c x b, e1 = a x c, e2 = b x a are differences of two 48-bit products: one product rounded, its
+// rounding error recovered exactly by an fma, the other folded into the difference by a second fma -- each weight is good to a few
+// 2^-24 of ITSELF, however thin the sliver (a plain FP32 difference of the products would be good to 2^-24 of the PRODUCTS, which
+// for a pixel far from a sub-pixel-wide primitive's vertices is more than the whole area).  Barycentrics, perspective weights and
+// the division by their sum collapse into one reciprocal: attr = sum(e_i rw_i a_i) / sum(e_i rw_i).
+__device__ __forceinline__ uint32_t shade_from_records_fast(const FrameParams &P, const ShadeTables &S, uint32_t i, uint32_t j, uint32_t odd,
+                                                            const VertexRec &r0, const VertexRec &r1, const VertexRec &r2, int32_t px, int32_t py)
+{
+    const int32_t Px = px * 256 + 128, Py = py * 256 + 128;
+    const float ax = (float)(r0.X - Px), ay = (float)(r0.Y - Py), bx = (float)(r1.X - Px), by = (float)(r1.Y - Py);
+    const float cx = (float)(r2.X - Px), cy = (float)(r2.Y - Py);
+    auto cross = [](float ux, float uy, float vx, float vy) -> float {     // ux vy - uy vx
+        const float q = uy * vx;
+        return fmaf(ux, vy, -q) - fmaf(uy, vx, -q);
+    };
+    const float q0 = cross(cx, cy, bx, by) * r0.rw, q1 = cross(ax, ay, cx, cy) * r1.rw, q2 = cross(bx, by, ax, ay) * r2.rw;
+    const float rQ = __builtin_amdgcn_rcpf((q0 + q1) + q2);
+    const float height = fmaf(q2, r2.h, fmaf(q1, r1.h, q0 * r0.h)) * rQ;
+    // xz (terrain.wgsl:64): vertex 0 = (i + odd, j), vertex 1 = (i, j + 1), vertex 2 = (i + 1, j + odd), one grid pitch apart
+    const float xi = fmaf((float)i, P.step, -1.5f), zj = fmaf((float)j, P.step, -1.5f);
+    const float x = fmaf(P.step * rQ, (odd ? q0 : 0.0f) + q2, xi);
+    const float z = fmaf(P.step * rQ, q1 + (odd ? q2 : 0.0f), zj);
+    return fragment_shader_fast(P, S, height, x, z);
+}
+
+// cell / nm1 without a division: cell < 2^26, nm1 < 2^13; the host chose div_m, div_s so that the product's high word shifted is exact
+__device__ __forceinline__ uint32_t cell_row(const FrameParams &P, uint32_t cell) { return __umulhi(cell, P.div_m) >> P.div_s; }
+
 // CLIPPED = false: the caller never put a near/far-clipped primitive into the visibility tile (the fast tile kernel), so the
 // clipping code -- calls, stack arrays, scratch memory, the vertex shader -- is not compiled in at all.
-template <bool CLIPPED>
+// FAST: the fast fragment path above (the host picks it for VF_PRECISION_FAST frames in REFERENCE shade mode).
+template <bool CLIPPED, bool FAST>
 __device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V, const ShadeTables &S, uint32_t prim, int32_t px, int32_t py)
 {
     // indices [a,c,b, b,c,d] (src/terrain/mod.rs:578-582): even = (a, c, b), odd = (b, c, d)
     const uint32_t cell = prim >> 1, odd = prim & 1u;
-    const uint32_t j = cell / P.nm1, i = cell - j * P.nm1;
+    const uint32_t j = cell_row(P, cell), i = cell - j * P.nm1;
     const uint32_t li = i & 7u, lj = j & 7u;
     const size_t b = (size_t)(j >> 3) * P.nb + (i >> 3);
     if constexpr (CLIPPED) {
@@ -725,7 +804,7 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V,
                 load_prim(P, V.hblk, prim, v[0], v[1], v[2]);
                 float attr[3] = { 0.f, 0.f, 0.f };
                 if (!clipped_attributes(v, P.hw, P.hh, P.W, P.H, px, py, attr)) return P.clear_rgba;   // unreachable when the visibility tile is consistent
-                return fragment_shader(P, S, attr);
+                return FAST ? fragment_shader_fast(P, S, attr[0], attr[1], attr[2]) : fragment_shader(P, S, attr);
             }
         }
     }
@@ -733,7 +812,8 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V,
     const uint32_t l0 = odd ? va + 1u : va, l1 = va + kBlockVerts, l2 = odd ? va + kBlockVerts + 1u : va + 1u;
     const size_t base = b * kBlockStride;
     const VertexRec r0 = V.vtx[base + l0], r1 = V.vtx[base + l1], r2 = V.vtx[base + l2];   // three 16-byte loads: all a vertex contributes
-    return shade_from_records(P, S, i, j, odd, r0, r1, r2, px, py);
+    if constexpr (FAST) return shade_from_records_fast(P, S, i, j, odd, r0, r1, r2, px, py);
+    else return shade_from_records(P, S, i, j, odd, r0, r1, r2, px, py);
 }
 
 // does the block's pixel box touch the tile, and is any pixel of the overlap still open (not final)?
@@ -920,7 +1000,10 @@ __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_
 // Weights are FEEDBACK: the time (10 ns ticks, summed over its strips) k_tile spent on the tile in the previous frame
 // (0 on the first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
 // never the result, so a stale value after a camera jump costs time, not correctness.
-__global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ background,
+// `flags_out`: this frame's per-tile word (bit 0 background, bits 8.. the cut).  Not the `background` array itself: when the plan is
+// not fresh, `last_flags` IS this plan state's `background` (the frame two back), and other workgroups of this launch still read
+// their neighbours' old entries -- k_plan_sort, which runs after every workgroup of this kernel, moves the new words over.
+__global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__restrict__ row_boxes, uint32_t *__restrict__ flags_out,
                                               uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                               const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
@@ -1002,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             const uint32_t cut = lg | (lgs << 4);
             const bool same_cut = seen == tile_time(blockIdx.x) && seen != 0u && ((last_flags[blockIdx.x] >> 8) & 0x3Fu) == cut;
             const uint32_t *piece_time = last_blocks + (size_t)P.ntx * P.nty + 1u + (size_t)blockIdx.x * 64u;
-            background[blockIdx.x] = cut << 8;              // busy; the pieces it is cut into (read back with its time, above)
+            flags_out[blockIdx.x] = cut << 8;               // busy; the pieces it is cut into (read back with its time, two frames on)
             const uint32_t parts = 1u << lg, slices = 1u << lgs;
             const uint32_t at = atomicAdd(work_count, parts * slices);
             for (uint32_t p = 0; p < parts; ++p)
@@ -1014,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
     }
     // background tile: only flagged here.  The plan kernels touch nothing but plan state, so they may run on a side stream
     // while the previous frame is still being drawn; k_clear, on the frame's own stream, does the clearing.
-    if (threadIdx.x == 0) background[blockIdx.x] = 1u;
+    if (threadIdx.x == 0) flags_out[blockIdx.x] = 1u;
 }
 
 // Background tiles: clear colour (src/terrain/mod.rs:421).  Whole tiles in a 16-byte aligned layout take 16 bytes per lane
@@ -1055,11 +1138,13 @@ __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__
 // longer than 4096 are sorted in independent 4096-item runs, which is all the scheduler needs) and clear this plan state's
 // per-tile feedback counters (the plan has read them).
 __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
-                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles)
+                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles,
+                                                    const uint32_t *__restrict__ flags_new, uint32_t *__restrict__ background, uint32_t nlocal)
 {
     __shared__ uint2 s[4096];
     const uint32_t n = *work_count;
     for (uint32_t k = threadIdx.x; k < ntiles; k += 1024) last_blocks[k] = 0u;       // this frame's tile kernel adds its times
+    for (uint32_t k = threadIdx.x; k < nlocal; k += 1024) background[k] = flags_new[k];   // the plan is done reading the old words
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
         uint32_t cap = 2;
@@ -1094,7 +1179,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 //      conservative); a fully final tile stops early;
 //   5. fragment stage on the LDS tile.
 #ifdef VF_PHASE_PROF   // diagnostics build: per-phase shader-clock cycles and event counts (vf_terrain_debug_phase_cycles)
-#define VF_PH_INIT uint64_t ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..11: parts of the set-up
+#define VF_PH_INIT uint64_t ph_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..15: parts of the set-up; 16, 17: parts of `vertex`
 #define VF_PH(p) { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[p] += ph_now - ph_last; ph_last = ph_now; }
 #else
 #define VF_PH_INIT
@@ -1106,7 +1191,7 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
 // of the main kernel is what lets it live in 96 vector registers (VF_TILE_MIN_WAVES, vf_device.h: the next frame's set-up kernel
 // shares the CUs with it); the 28 registers it spills at that cap are spilled outside the block loop.
-template <bool WRITE_VIS, bool COMPLETE>
+template <bool WRITE_VIS, bool COMPLETE, bool FAST>
 __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameParams P, SetupView V, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
@@ -1146,7 +1231,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
 #ifdef VF_DBG_PULLS
     __shared__ uint32_t s_dbg;
 #endif
-    __shared__ float s_lut[256 * 3];
+    __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
     __shared__ float s_thr[256];
     __shared__ uint32_t s_per[65];                         // [survivors]: lanes per survivor | ceil(2^16 / that) << 7 | survivors per round << 24
 
@@ -1156,7 +1241,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
-    for (int k = tid; k < 768; k += kTileThreads) s_lut[k] = lut_linear[k];
+    for (int k = tid; k < kLutFloats; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
     if (tid <= 64u) { const uint32_t per = tid ? 64u / tid : 64u; s_per[tid] = per | (((65536u + per - 1u) / per) << 7) | ((64u / per) << 24); }
     const uint32_t nwork = *work_count;
@@ -1407,8 +1492,13 @@ next_item:
                 const unsigned long long alive_e = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.x) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.y) << 32);
                 const unsigned long long alive_o = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.z) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.w) << 32);
                 const uint32_t rflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_lo.z);
+                VF_PH(16)                                  // (diagnostics: the record is here)
                 sXY[wave][lane] = xa;
                 if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
+#ifdef VF_PHASE_PROF
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                VF_PH(17)                                  // (diagnostics: the vertices are here and staged)
                 if (!COMPLETE && (rflags & kRecGeneric)) { if (lane == 0) s_redo = 1u; }   // rare: clipped / oversized -> the COMPLETE launch
                 // the alive primitives as a dense list: cell c's even primitive sits at popcount(alive_e below c), its odd one behind all
                 // the even ones -- every lane of the classification below then holds a primitive that can draw
@@ -1578,7 +1668,7 @@ next_item:
             if (px > T.px_hi || py > T.py_hi) continue;
             const uint32_t id = s_vis[vis_index(lx, ly)];
             const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-            rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
             if (WRITE_VIS) vis_out[o] = id;
         }
     } else {
@@ -1590,7 +1680,7 @@ next_item:
             const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
             const uint32_t id = s_vis[vis_index(lx, ly)];
             const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-            rgba[o] = id ? shade_pixel<COMPLETE>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
             if (WRITE_VIS) vis_out[o] = id;
         }
     }
@@ -1622,6 +1712,7 @@ next_item:
         if (lane == 0) {
             for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
             for (int p = 8; p < 16; ++p) atomicAdd(&ph[8 + p], (unsigned long long)ph_acc[p]);
+            atomicAdd(&ph[30], (unsigned long long)ph_acc[16]); atomicAdd(&ph[31], (unsigned long long)ph_acc[17]);
             atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
             atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
         }
@@ -1642,41 +1733,176 @@ next_item:
 // ---------------------------------------------------------------------------------------------
 // Diagnostics: the fragment stage as a launch of its own (vf_terrain_debug_fragment_stage).  Visibility (H, W) u32 in HBM ->
 // RGBA8 through the same shade_pixel the tile kernel runs on its LDS tile: fs_main + sRGB store
-// (src/shaders/terrain.wgsl:69-91).  One thread per pixel, one 256-pixel row segment per workgroup; streaming, 4 B read +
-// 4 B written per pixel plus the heights of the visible primitives.
+// (src/shaders/terrain.wgsl:69-91).  Streaming: 4 B read + 4 B written per pixel plus the records of the visible primitives.
+//
+// What bounds it is neither arithmetic nor HBM bandwidth but the L1's miss handling (rocprofv3 --pmc on the row-segment form
+// this replaces, fill camera: 52 distinct cache lines per 64-lane record gather, 64 % of them L1 misses, the L1 stalled on
+// pending L2 data 65 % of the launch, 344 cycles per L2 round trip -- and halving the instruction count moved the time by 4 %).
+// A pixel's three vertex records sit in two 144-byte vertex rows of its block; pixels next to each other ALONG A ROW share
+// few of them on a noise terrain (the visible primitive jumps between cell rows), pixels in a small 2-D neighbourhood share
+// many.  So a wave takes an 8 x 8 pixel tile (four of them, side by side, per workgroup: every visibility / RGBA row segment
+// of the 32 x 8 region is one whole 128-byte line), and the regions are dealt to the workgroups so that each XCD -- each L2 --
+// owns a contiguous band of region columns: vertically and horizontally adjacent regions meet in the same L2.
+// Persistent workgroups, tables staged once, the next region's visibility words requested before the current one is shaded.
 // ---------------------------------------------------------------------------------------------
-template <bool CLIPPED>
+// Which region a workgroup takes next.  Workgroups are dealt to the XCDs round-robin (workgroup b runs on XCD b % 8, each XCD with its
+// own L2): the regions are grouped into super-tiles of kSuper x kSuper regions, super-tile (sx, sy) belongs to XCD (sx + 3 sy) % 8 --
+// every XCD gets an eighth of every part of the frame (a terrain that covers the middle of the picture loads them all alike) -- and
+// the workgroups of an XCD walk its super-tiles region by region, so that neighbouring regions are shaded at the same time from the
+// same L2.  Frames whose region columns do not divide into 8 super-tile columns are walked in plain row-major order.
+struct RegionWalk {
+    static constexpr uint32_t kSuper = 4;
+    uint32_t nrx, nry, per_row, xcd, stride, k, total;   // per_row: super-tiles of one XCD per super-tile row (0: plain walk)
+    __device__ __forceinline__ void init(uint32_t nrx_, uint32_t nry_)
+    {
+        nrx = nrx_; nry = nry_;
+        const bool banded = nrx % (8u * kSuper) == 0u && gridDim.x % 8u == 0u;
+        per_row = banded ? nrx / (8u * kSuper) : 0u;
+        xcd = banded ? blockIdx.x % 8u : 0u;
+        stride = banded ? gridDim.x / 8u : gridDim.x;
+        k = banded ? blockIdx.x / 8u : blockIdx.x;
+        total = banded ? per_row * ((nry + kSuper - 1u) / kSuper) * kSuper * kSuper : nrx * nry;
+    }
+    __device__ __forceinline__ bool valid() const { return k < total; }
+    // (rx, ry) of sequence number kk; ry may lie beyond nry in the last super-tile row (the callers' bounds checks skip those)
+    __device__ __forceinline__ void at(uint32_t kk, uint32_t &rx, uint32_t &ry) const
+    {
+        if (per_row == 0u) { ry = kk / nrx; rx = kk - ry * nrx; return; }
+        const uint32_t st = kk / (kSuper * kSuper), in = kk % (kSuper * kSuper);
+        const uint32_t sy = st / per_row, m = st - sy * per_row;
+        const uint32_t sx = ((xcd + 8u * 3u - (3u * sy) % 8u) % 8u) + 8u * m;      // (sx + 3 sy) % 8 == xcd
+        rx = sx * kSuper + in % kSuper; ry = sy * kSuper + in / kSuper;
+    }
+};
+
+template <bool CLIPPED, bool FAST>
 __global__ __launch_bounds__(256) void k_resolve(FrameParams P, SetupView V, const float *__restrict__ lut_linear,
                                                  const float *__restrict__ thresh, const uint32_t *__restrict__ vis,
                                                  uint32_t *__restrict__ rgba, uint32_t *__restrict__ covered)
 {
-    // Persistent: a few workgroups per CU walk the frame's 256-pixel row segments with a grid stride -- the tables are staged once
-    // per workgroup, not once per segment, and a segment's visibility words are requested before the previous segment is shaded
-    // (one workgroup per segment was a chain of three dependent round trips -- tables, visibility, vertex records -- per 256 pixels:
-    // 0.116 ms for C4's default frame).
-    __shared__ float s_lut[256 * 3];
+    __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
     __shared__ float s_thr[256];
-    for (int k = threadIdx.x; k < 768; k += 256) s_lut[k] = lut_linear[k];
+    for (int k = threadIdx.x; k < kLutFloats; k += 256) s_lut[k] = lut_linear[k];
     s_thr[threadIdx.x] = thresh[threadIdx.x];
     __syncthreads();
     const ShadeTables S = { s_lut, s_thr };
-    const uint32_t segs = (P.W + 255u) / 256u, total = segs * P.H;
-    auto fetch = [&](uint32_t seg) -> uint32_t {
-        const uint32_t py = seg / segs, px = (seg - py * segs) * 256u + threadIdx.x;
-        return px < P.W ? vis[(size_t)py * P.W + px] : 0u;
+    // lane -> pixel of the workgroup's 32 x 8 region: wave w holds the 8 x 8 tile at x = 8 w
+    const uint32_t lx = (threadIdx.x >> 6) * 8u + (threadIdx.x & 7u), ly = (threadIdx.x >> 3) & 7u;
+    RegionWalk R;
+    R.init((P.W + 31u) / 32u, (P.H + 7u) / 8u);
+    auto fetch = [&](uint32_t kk) -> uint32_t {
+        uint32_t rx, ry;
+        R.at(kk, rx, ry);
+        const uint32_t px = rx * 32u + lx, py = ry * 8u + ly;
+        return px < P.W && py < P.H ? vis[(size_t)py * P.W + px] : 0u;
     };
     uint32_t ncov = 0;
-    uint32_t seg = blockIdx.x;
-    uint32_t id_next = seg < total ? fetch(seg) : 0u;
-    while (seg < total) {
+    uint32_t id_next = R.valid() ? fetch(R.k) : 0u;
+    while (R.valid()) {
         const uint32_t id = id_next;
-        const uint32_t nseg = seg + gridDim.x;
-        if (nseg < total) id_next = fetch(nseg);
-        const uint32_t py = seg / segs, px = (seg - py * segs) * 256u + threadIdx.x;
-        if (px < P.W) rgba[(size_t)py * P.W + px] = id ? shade_pixel<CLIPPED>(P, V, S, id - 1u, (int32_t)px, (int32_t)py) : P.clear_rgba;
+        const uint32_t kn = R.k + R.stride;
+        if (kn < R.total) id_next = fetch(kn);
+        uint32_t rx, ry;
+        R.at(R.k, rx, ry);
+        const uint32_t px = rx * 32u + lx, py = ry * 8u + ly;
+        if (px < P.W && py < P.H) rgba[(size_t)py * P.W + px] = id ? shade_pixel<CLIPPED, FAST>(P, V, S, id - 1u, (int32_t)px, (int32_t)py) : P.clear_rgba;
         ncov += (uint32_t)__popcll(__ballot(id != 0u));
-        seg = nseg;
+        R.k = kn;
     }
+    if (covered && (threadIdx.x & 63u) == 0u && ncov) atomicAdd(covered, ncov);
+}
+
+// The same for rows of a multiple of four pixels (and no clipped primitives in the frame): the HBM side moves 16 bytes per lane -- a lane
+// loads the visibility words of four consecutive pixels of a row and stores their four colours, a wave covers 16 x 16 pixels, the
+// workgroup's four waves a 32 x 32 region -- while the shading still runs on compact 8 x 8 tiles: a wave that holds any covered
+// pixel passes its 256 words through LDS (row pitch 20 words: 16-byte aligned rows, at most two-way bank conflicts) and shades the four
+// 8 x 8 quarters of its area one pixel per lane, as above.  Background regions (84 % of C4's default frame) cost one 16-byte
+// load and one 16-byte store per lane; covered ones keep the 2-D locality that the L1 needs.
+#ifndef VF_RESOLVE_UNROLL
+#define VF_RESOLVE_UNROLL 1
+#endif
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_resolve4(FrameParams P, SetupView V, const float *__restrict__ lut_linear,
+                                                  const float *__restrict__ thresh, const uint4 *__restrict__ vis,
+                                                  uint4 *__restrict__ rgba, uint32_t *__restrict__ covered)
+{
+    constexpr uint32_t kPitch = 20;
+    __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
+    __shared__ float s_thr[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_px[4][16 * kPitch];
+    for (int k = threadIdx.x; k < kLutFloats; k += 256) s_lut[k] = lut_linear[k];
+    s_thr[threadIdx.x] = thresh[threadIdx.x];
+    __syncthreads();
+    const ShadeTables S = { s_lut, s_thr };
+    const uint32_t W4 = P.W / 4u;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // HBM side: lane -> quad (lane & 3) of row (lane >> 2) of the wave's 16 x 16 area; the waves sit 2 x 2 in the region
+    const uint32_t lq = (wv & 1u) * 4u + (lane & 3u), ly = (wv >> 1) * 16u + (lane >> 2);
+    uint32_t *const sw = s_px[wv];
+    uint32_t *const mine4 = sw + (lane >> 2) * kPitch + (lane & 3u) * 4u;
+    RegionWalk R;
+    R.init((W4 + 7u) / 8u, (P.H + 31u) / 32u);
+    auto fetch = [&](uint32_t kk) -> uint4 {
+        uint32_t rx, ry;
+        R.at(kk, rx, ry);
+        const uint32_t q = rx * 8u + lq, py = ry * 32u + ly;
+        if (!(q < W4 && py < P.H)) return make_uint4(0u, 0u, 0u, 0u);
+#ifdef VF_RESOLVE_NT
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(vis) + ((size_t)py * W4 + q));   // read once: do not keep it in the caches
+        return make_uint4(v.x, v.y, v.z, v.w);
+#else
+        return vis[(size_t)py * W4 + q];
+#endif
+    };
+    uint32_t ncov = 0;
+    // visibility words are requested kAhead regions ahead: with the few waves per CU that suit the record gathers (below), one
+    // 16-byte load in flight per lane would leave HBM idle (bytes in flight = bandwidth x latency)
+#ifndef VF_RESOLVE_AHEAD
+#define VF_RESOLVE_AHEAD 3
+#endif
+    constexpr int kAhead = VF_RESOLVE_AHEAD;
+    uint4 ring[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) ring[a] = R.k + (uint32_t)a * R.stride < R.total ? fetch(R.k + (uint32_t)a * R.stride) : make_uint4(0u, 0u, 0u, 0u);
+    while (R.valid()) {
+        const uint4 id = ring[0];
+        const uint32_t kn = R.k + R.stride, kf = R.k + (uint32_t)kAhead * R.stride;
+#pragma unroll
+        for (int a = 0; a + 1 < kAhead; ++a) ring[a] = ring[a + 1];
+        if (kf < R.total) ring[kAhead - 1] = fetch(kf);
+        uint32_t rx, ry;
+        R.at(R.k, rx, ry);
+        const uint32_t q = rx * 8u + lq, py = ry * 32u + ly;
+        uint4 out = make_uint4(P.clear_rgba, P.clear_rgba, P.clear_rgba, P.clear_rgba);
+        if (__ballot((id.x | id.y | id.z | id.w) != 0u) != 0ull) {            // (wave-uniform)
+            *reinterpret_cast<uint4 *>(mine4) = id;
+            __builtin_amdgcn_wave_barrier();               // LDS operations of one wave complete in order; keep the compiler from reordering
+            const int32_t ax = (int32_t)((rx * 8u + (wv & 1u) * 4u) * 4u), ay = (int32_t)(ry * 32u + (wv >> 1) * 16u);   // the wave's area
+#pragma unroll VF_RESOLVE_UNROLL
+            for (uint32_t t8 = 0; t8 < 4u; ++t8) {         // its four 8 x 8 quarters, one pixel per lane
+                const uint32_t sx = (t8 & 1u) * 8u + (lane & 7u), sy = (t8 >> 1) * 8u + (lane >> 3);
+                uint32_t *const w = sw + sy * kPitch + sx;
+                const uint32_t pid = *w;
+                *w = pid ? shade_pixel<false, FAST>(P, V, S, pid - 1u, ax + (int32_t)sx, ay + (int32_t)sy) : P.clear_rgba;
+            }
+            __builtin_amdgcn_wave_barrier();
+            out = *reinterpret_cast<const uint4 *>(mine4);
+            __builtin_amdgcn_wave_barrier();               // (the next region's words go to the same place)
+        }
+        if (q < W4 && py < P.H) {
+#ifdef VF_RESOLVE_NT
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            u4v o; o.x = out.x; o.y = out.y; o.z = out.z; o.w = out.w;
+            __builtin_nontemporal_store(o, reinterpret_cast<u4v *>(rgba) + ((size_t)py * W4 + q));
+#else
+            rgba[(size_t)py * W4 + q] = out;
+#endif
+        }
+        ncov += (id.x ? 1u : 0u) + (id.y ? 1u : 0u) + (id.z ? 1u : 0u) + (id.w ? 1u : 0u);
+        R.k = kn;
+    }
+    for (int o = 32; o > 0; o >>= 1) ncov += __shfl_xor(ncov, o);
     if (covered && (threadIdx.x & 63u) == 0u && ncov) atomicAdd(covered, ncov);
 }
 

@@ -244,6 +244,15 @@ public:
         else if (mode == "spec_t32") check(vf_terrain_set_shade_mode(t, VF_SHADE_SPEC_T32));
         else throw py::value_error("shade mode must be 'reference' or 'spec_t32'");
     }
+    // extension: "fast" (default) = hardware rcp / rsq / sin / cos / log / exp in the fragment stage, within 1 LSB of "exact"
+    // (IEEE binary32 in a fixed order, the CPU oracle bit for bit); visibility is identical
+    void set_shade_precision(const std::string &precision)
+    {
+        Borrow b(busy);
+        if (precision == "exact") check(vf_terrain_set_shade_precision(t, VF_PRECISION_EXACT));
+        else if (precision == "fast") check(vf_terrain_set_shade_precision(t, VF_PRECISION_FAST));
+        else throw py::value_error("shade precision must be 'exact' or 'fast'");
+    }
     py::dict last_timings()
     {
         Borrow b(busy);
@@ -545,6 +554,7 @@ py::class_<T> bind_terrain(py::module_ &m, const char *name)
         .def("debug_visibility", &T::debug_visibility)
         .def("set_shard", &T::set_shard, py::arg("rank"), py::arg("nranks"), py::arg("band_h") = 64)
         .def("set_shade_mode", &T::set_shade_mode, py::arg("mode"))
+        .def("set_shade_precision", &T::set_shade_precision, py::arg("precision"))
         .def("enable_timing", &T::enable_timing, py::arg("on") = true)
         .def("last_timings", &T::last_timings);
 }
