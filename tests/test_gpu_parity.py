@@ -306,6 +306,28 @@ def test_c4_default_camera_full_oracle_parity(c4, oracle, luts):
     compare_both(t, ref_rgba, ref_vis)
 
 
+def test_c4_one_shot_frame_is_planned(c4, cabi, oracle, luts):
+    """The reference's usage is one-shot -- construct, render once (src/terrain/mod.rs:410-491).  A fresh handle has no tile times:
+    its first frame is planned from the static estimate (k_plan_estimate), must already cut the heavy far-field tiles into strips,
+    and must of course be the same picture (EXACT precision: the oracle's, byte for byte)."""
+    _, h, W, H, G = c4
+    u = oracle.default_uniforms(1, W, H)
+    ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h); t.set_uniforms(u); t.set_shade_precision(EXACT)
+        t.enable_timing(True)
+        t.render()                                                      # the ONE frame
+        rgba = t.read_rgba()
+        codes = t.item_stats()[:, 0]
+        t.enable_timing(False)
+        assert int(((codes >> 24) & 7).astype(bool).sum()) > 0, "the first frame was not cut into strips"
+        assert np.array_equal(rgba, ref_rgba)
+        assert np.array_equal(t.read_visibility(), ref_vis)
+    finally:
+        t.close()
+
+
 def test_c4_fill_camera_full_oracle_parity(c4, oracle, luts):
     """The bench's other_camera (top-down, 73 % coverage) at full size against the oracle -- rendered a
     few times first so that the compared frame is planned with scheduling feedback, as the timed frames are."""

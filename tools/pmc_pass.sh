@@ -2,6 +2,7 @@
 # One rocprofv3 --pmc pass over bench.py (GPU box; counters in their own run, as the pool requires):
 #   tools/pmc_pass.sh <outdir under gpurun_out> "<COUNTER ...>" [bench args...]
 # prints per-kernel averages (tools/pmc_sq_summary.py) for the tile / set-up kernels; CSV stays under gpurun_out/<outdir>/
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}"
 out=gpurun_out/$1; ctr=$2; shift; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of one rank of N (tools/exp_rank_trace.py, 40 frames back to back) in two rocprofv3 --pmc passes:
 #   tools/pmc_rank.sh <outdir under gpurun_out> [rank n skew]      -> per-kernel averages printed, CSVs under gpurun_out/<outdir>/
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}"
 out=gpurun_out/$1; shift
 mkdir -p "$out"
 R="$GRAFT_REPO_ROOT"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel timeline of one rank of N (tools/exp_rank_trace.py) under rocprofv3: tools/prof_rank.sh <outdir> [rank n]
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}"
 out=gpurun_out/$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of one bench.py run (GPU box): tools/prof_stats.sh <outdir under gpurun_out> [bench args...]
 # prints the per-kernel table; the CSVs stay under gpurun_out/<outdir>/
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}"
 out=gpurun_out/$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp

@@ -2,6 +2,7 @@
 # Everything the round's profiles/ files are made of, in one GPU-box session:  tools/profile_round.sh <tag>   (e.g. r02)
 # Writes gpurun_out/<tag>/...; tools/install_profiles.py <tag> then copies the summaries into profiles/ and refreshes profiles/pmc_traffic.json.
 # rocprofv3 --pmc passes are separate runs with counters only (no trace domains), as the pool requires.
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets it)}"
 tag=$1
 out=gpurun_out/$tag
 mkdir -p "$out"

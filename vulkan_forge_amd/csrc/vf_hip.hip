@@ -644,6 +644,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // (one more frame after the motion stops: the frame before last still shows the old view, the last one the new)
     // ... and the second frame of a handle: its own plan state has no times yet, the first frame's has
     const bool fresh = t->camera_moving || t->was_moving || t->frames_since_reset == 1;
+    const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");   // no tile times at all yet: a static estimate stands in (k_plan_estimate)
     t->frames_since_reset++;
     t->was_moving = t->camera_moving;
     const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
@@ -670,7 +671,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t nsegs_all = t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks);
     uint32_t *seg_count = S.seg_list + nsegs_all;
     hipLaunchKernelGGL(k_block_boxes, dim3(t->nb + 1), dim3(t->nb > 256 ? 512 : 256), 0, side, P, t->d_bounds, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, rc_lo, rc_hi,
-                       fresh ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count, S.recs, S.seg_list, seg_count);
+                       fresh || first ? (const uint32_t *)nullptr : S.feedback, t->ntx * t->nty, quantum, S.work_count, S.recs, S.seg_list, seg_count);
     // vertex stage + tile-independent culling, once per frame (streams ~1.3 KB per block into this frame's plan state): needs the
     // block boxes only, so it runs on a second stream beside k_plan / k_plan_sort -- all of them under the previous frame's tile kernel
     VF_HIP_TRY(hipEventRecord(S.boxed, side));
@@ -685,6 +686,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         if (fresh) {
             VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));         // (the block boxes above did not need to wait)
             hipLaunchKernelGGL(k_quantum, dim3(1), dim3(512), 0, side, O.feedback, t->ntx * t->nty, quantum);
+        } else if (first) {
+            VF_HIP_TRY(hipStreamWaitEvent(side, S.set_up, 0));       // the estimate reads the set-up pass's block records
+            hipLaunchKernelGGL(k_plan_estimate, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.recs, S.cap_seg, S.cap_rad, rc_lo, rc_hi, S.feedback);
+            hipLaunchKernelGGL(k_quantum, dim3(1), dim3(512), 0, side, S.feedback, t->ntx * t->nty, quantum);
         }
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.flags_new, S.work, S.work_count,

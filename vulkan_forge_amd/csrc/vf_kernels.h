@@ -818,11 +818,11 @@ __device__ inline uint32_t shade_pixel(const FrameParams &P, const SetupView &V,
 
 // does the block's pixel box touch the tile, and is any pixel of the overlap still open (not final)?
 // conservative: does the segment (a, b) come within `rad` of the tile rectangle?  (slab test on the tile grown by rad)
-__device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, const TileCtx &T)
+__device__ __forceinline__ bool capsule_hits_rect(const float4 &seg, float rad, int32_t px_lo, int32_t px_hi, int32_t py_lo, int32_t py_hi)
 {
     if (!(rad < 1e30f)) return true;
-    const float ex0 = (float)T.px_lo - rad, ex1 = (float)(T.px_hi + 1) + rad;
-    const float ey0 = (float)T.py_lo - rad, ey1 = (float)(T.py_hi + 1) + rad;
+    const float ex0 = (float)px_lo - rad, ex1 = (float)(px_hi + 1) + rad;
+    const float ey0 = (float)py_lo - rad, ey1 = (float)(py_hi + 1) + rad;
     const float dx = seg.z - seg.x, dy = seg.w - seg.y;
     float t0 = 0.0f, t1 = 1.0f;
     if (fabsf(dx) < 1e-6f) { if (seg.x < ex0 || seg.x > ex1) return false; }
@@ -830,6 +830,10 @@ __device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, 
     if (fabsf(dy) < 1e-6f) { if (seg.y < ey0 || seg.y > ey1) return false; }
     else { const float inv = 1.0f / dy; const float a = (ey0 - seg.y) * inv, b = (ey1 - seg.y) * inv; t0 = fmaxf(t0, fminf(a, b)); t1 = fminf(t1, fmaxf(a, b)); }
     return t0 <= t1 + 1e-4f;
+}
+__device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, const TileCtx &T)
+{
+    return capsule_hits_rect(seg, rad, T.px_lo, T.px_hi, T.py_lo, T.py_hi);
 }
 
 __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const float4 &cap_seg, float cap_rad, const TileCtx &T)
@@ -997,9 +1001,103 @@ __device__ __forceinline__ void work_strip(uint32_t code, int32_t &px_lo, int32_
     px_lo = lo;
 }
 
-// Weights are FEEDBACK: the time (10 ns ticks, summed over its strips) k_tile spent on the tile in the previous frame
-// (0 on the first frame: then the number of block rows in reach).  They only steer scheduling -- order and strip splitting --
-// never the result, so a stale value after a camera jump costs time, not correctness.
+// Weights are FEEDBACK: the time (10 ns ticks, summed over its strips) k_tile spent on the tile in the previous frame.  They
+// only steer scheduling -- order and strip splitting -- never the result, so a stale value after a camera jump costs time, not
+// correctness.  A handle's FIRST frame has no times yet: k_plan_estimate stands in for them with a static estimate from the
+// block ranges (below), so that the one-shot render of the reference's usage (construct, render_png once: src/terrain/mod.rs:410-491)
+// is planned -- cut into strips, heaviest first -- like any other frame.
+
+// Block rows that reach tile column `tcol` within pixel rows [py_lo, py_hi]: their number (returned; 0 = background tile) and the
+// number of blocks in their [rc_lo, rc_hi) ranges (*est_out) -- the candidates the tile kernel will test, a little more than the
+// (tile, block) pairs it will draw.  One workgroup of 256 threads; both results are workgroup-uniform after the call.
+__device__ __forceinline__ uint32_t tile_reach(const FrameParams &P, const PixelBox *__restrict__ row_boxes, const uint32_t *__restrict__ rc_lo,
+                                               const uint32_t *__restrict__ rc_hi, uint32_t tcol, int32_t py_lo, int32_t py_hi,
+                                               uint32_t *s_hits, uint32_t *s_est)
+{
+    if (threadIdx.x == 0) { *s_hits = 0; *s_est = 0; }
+    __syncthreads();
+    uint32_t hits = 0, est = 0;
+    for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
+        const PixelBox rr = row_boxes[r];
+        const uint32_t lo = rc_lo[tcol * P.nb + r], hi = rc_hi[tcol * P.nb + r];
+        if (lo < hi && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) { ++hits; est += hi - lo; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_xor(hits, o); est += __shfl_xor(est, o); }
+    if ((threadIdx.x & 63u) == 0 && hits) { atomicAdd(s_hits, hits); atomicAdd(s_est, est); }
+    __syncthreads();
+    return *s_hits;
+}
+// ticks (10 ns) a tile with `blocks` candidate blocks is expected to cost: 0.25 us per block (C4: 0.2 .. 0.35 us per pair at the
+// default camera, more for near blocks) -- only ratios between tiles matter, the split quantum is derived from the same numbers
+__device__ __forceinline__ uint32_t static_ticks(uint32_t blocks) { return max(blocks * 25u, 1u); }
+
+// First frame of a handle: a static estimate written where k_plan expects the previous frame's tile times (and the time of the
+// tile's only piece); k_quantum then derives the split quantum from them.  What a tile costs is the (tile, block) pairs it draws
+// before all its pixels are final, so the estimate walks the tile's block rows the way the tile kernel does -- nearest first, in
+// passes of 32 rows, 8 lanes per row -- and counts the blocks whose EXACT pixel box (the set-up pass's block record: on a first
+// frame nothing is there to overlap the plan with, so it may wait for the set-up) and capsule meet the tile, until the tile's
+// top strip is buried: every one of its eight 8 x 8-pixel cells inside the boxes of kEstDepth blocks.  Boxes are not coverage (a
+// noise terrain fills a tenth of a block's box), hence a depth, not a single layer; and the TOP strip because painter's order
+// draws the near rows first and they sit lowest on the screen: a tile on the silhouette keeps sky in its top strip and is
+// counted to its last row -- those are the frame's heaviest tiles -- while an interior tile stops after the rows that bury it.
+#ifndef VF_EST_DEPTH
+#define VF_EST_DEPTH 24
+#endif
+__device__ __forceinline__ bool capsule_hits_rect(const float4 &seg, float rad, int32_t px_lo, int32_t px_hi, int32_t py_lo, int32_t py_hi);
+__global__ __launch_bounds__(256) void k_plan_estimate(FrameParams P, const PixelBox *__restrict__ row_boxes, const BlockRec *__restrict__ recs,
+                                                       const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
+                                                       const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
+                                                       uint32_t *__restrict__ feedback)
+{
+    constexpr uint32_t kEstDepth = VF_EST_DEPTH;
+    __shared__ uint32_t s_est, s_top[8], s_stop;
+    int32_t px_lo, px_hi, py_lo, py_hi;
+    const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
+    if (threadIdx.x < 8u) s_top[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) { s_est = 0; s_stop = 0; }
+    __syncthreads();
+    const uint32_t sub = threadIdx.x & 7u, rsub = threadIdx.x >> 3;          // 8 lanes share a row, 32 rows per pass
+    uint32_t est = 0;
+    for (uint32_t base = 0; base < P.nb; base += 32u) {
+        const uint32_t k = base + rsub;
+        if (k < P.nb) {
+            const uint32_t r = P.nb - 1u - k;                                   // descending rows = descending primitive ids = the tile kernel's order
+            const PixelBox rr = row_boxes[r];
+            const uint32_t lo = rc_lo[tp.tx * P.nb + r], hi = rc_hi[tp.tx * P.nb + r];
+            if (lo < hi && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi)
+                for (uint32_t bx = lo + sub; bx < hi; bx += 8u) {
+                    const uint4 rw = *reinterpret_cast<const uint4 *>(recs + r * P.nb + bx);        // box, flags, count
+                    const PixelBox b = PixelBox{ (int16_t)(rw.x & 0xFFFFu), (int16_t)(rw.x >> 16), (int16_t)(rw.y & 0xFFFFu), (int16_t)(rw.y >> 16) };
+                    if (!(b.x0 <= b.x1 && b.x1 >= px_lo && b.x0 <= px_hi && b.y1 >= py_lo && b.y0 <= py_hi)) continue;
+                    if (!capsule_hits_rect(cap_seg[r * P.nb + bx], cap_rad[r * P.nb + bx], px_lo, px_hi, py_lo, py_hi)) continue;
+                    // what the pair costs: one round trip for the block (2 ticks of the workgroup's time) + its alive primitives that
+                    // reach the tile -- the share of the block's box that lies inside the tile -- at 1.8 ticks each (C4, measured)
+                    const float ov = (float)((min((int32_t)b.x1, px_hi) - max((int32_t)b.x0, px_lo) + 1) * (min((int32_t)b.y1, py_hi) - max((int32_t)b.y0, py_lo) + 1));
+                    const float area = (float)(((int32_t)b.x1 - (int32_t)b.x0 + 1) * ((int32_t)b.y1 - (int32_t)b.y0 + 1));
+                    est += 32u + (uint32_t)(29.0f * (float)rw.w * ov / area);                          // sixteenths of a tick
+                    if ((int32_t)b.y0 <= py_lo && (int32_t)b.y1 >= py_lo + 7)      // spans the top strip: its cells inside the box
+                        for (int32_t c = max(((int32_t)b.x0 - px_lo + 7) >> 3, 0); c <= min(((int32_t)b.x1 - px_lo - 7) >> 3, 7); ++c) atomicAdd(&s_top[c], 1u);
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t least = s_top[0];
+            for (int c = 1; c < 8; ++c) least = min(least, s_top[c]);
+            s_stop = least >= kEstDepth ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_stop) break;                                                      // (uniform)
+    }
+    for (int o = 32; o > 0; o >>= 1) est += __shfl_xor(est, o);
+    if ((threadIdx.x & 63u) == 0 && est) atomicAdd(&s_est, est);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticks = max(s_est / 16u, 1u);         // (never 0: a tile without a time falls back to k_plan's looser count)
+        feedback[blockIdx.x] = ticks;
+        feedback[(size_t)P.ntx * P.nty + 1u + (size_t)blockIdx.x * 64u] = ticks;
+    }
+}
+
 // `flags_out`: this frame's per-tile word (bit 0 background, bits 8.. the cut).  Not the `background` array itself: when the plan is
 // not fresh, `last_flags` IS this plan state's `background` (the frame two back), and other workgroups of this launch still read
 // their neighbours' old entries -- k_plan_sort, which runs after every workgroup of this kernel, moves the new words over.
@@ -1009,21 +1107,10 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
                                               const uint32_t *__restrict__ rc_hi, uint32_t moving, const uint32_t *last_flags)
 {
-    __shared__ uint32_t s_hits;
+    __shared__ uint32_t s_hits, s_est;
     int32_t px_lo, px_hi, py_lo, py_hi;
     const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
-    if (threadIdx.x == 0) s_hits = 0;
-    __syncthreads();
-    uint32_t hits = 0;
-    const uint32_t tcol = tp.tx;
-    for (uint32_t r = threadIdx.x; r < P.nb; r += 256) {
-        const PixelBox rr = row_boxes[r];
-        hits += (rc_lo[tcol * P.nb + r] < rc_hi[tcol * P.nb + r] && rr.x0 <= rr.x1 && rr.y1 >= py_lo && rr.y0 <= py_hi) ? 1u : 0u;
-    }
-    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
-    if ((threadIdx.x & 63u) == 0 && hits) atomicAdd(&s_hits, hits);
-    __syncthreads();
-    const uint32_t total = s_hits;
+    const uint32_t total = tile_reach(P, row_boxes, rc_lo, rc_hi, tp.tx, py_lo, py_hi, &s_hits, &s_est);
     if (total) {
         if (threadIdx.x == 0) {
             // A tile's time is the sum over its strips, and strips repeat block work: cut in 16 it reports about twice what it
@@ -1055,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                         if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, tile_time((uint32_t)y * P.ntx + (uint32_t)x));
                     }
             }
-            const uint32_t weight = seen ? seen : total;
+            const uint32_t weight = seen ? seen : static_ticks(s_est);     // no time from any frame, nor from a neighbour: the blocks in reach
             // strips: 1, 2, 4, 8 or 16.  `mean` holds the split quantum published by k_plan_sort: four times the work one
             // item would carry if last frame's blocks were spread evenly over kTargetItems workgroups -- so a lightly loaded
             // GPU (one rank of a multi-GPU frame) cuts its few heavy tiles finer than a fully loaded one.
@@ -1622,6 +1709,9 @@ next_item:
         stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_dbg;        // (experiment: blocks pulled instead of blocks drawn)
 #else
         stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_blocks;
+#endif
+#ifdef VF_DBG_WEIGHT
+        stats[5 + 4 * item_idx] = work[item_idx].y;         // (experiment: the plan's weight of the item instead of the block count)
 #endif
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
