@@ -38,6 +38,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Before the HIP runtime starts (torch import): hardware queues for this process's streams.  A handle draws on one stream and plans /
+# sets up the next frame on two more; torch.distributed and the exchange add theirs; with the default of 4 queues two of them share
+# one and the next frame's set-up stops hiding under this frame's tile kernel (include/vf_hip.h, vf_ctx_stream).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed())
@@ -183,7 +187,12 @@ def main():
         return h
 
     t = new_handle()
-    stream = torch.cuda.current_stream().cuda_stream
+    # An explicit stream, made torch's current one: the raw handle of torch's DEFAULT stream is 0, which the C-ABI reads as "use the
+    # context's own stream" -- torch-side events and collectives would then be ordered against a stream nothing renders on.
+    # The library's own stream, and as torch's current one -- not one stream more (VF_BENCH_OWN_STREAM=1: a torch stream instead).
+    render_stream = torch.cuda.Stream(dev) if os.environ.get("VF_BENCH_OWN_STREAM") else torch.cuda.ExternalStream(t.stream_handle(), device=dev)
+    torch.cuda.set_stream(render_stream)
+    stream = render_stream.cuda_stream
     image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev) if (rank == 0 or c5) else None
     depth = 1 if args.serial else 2
     share = 1.0
@@ -205,21 +214,12 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             comm = t.dist_comm_init(uid[0], rank, world)
     frame_no = [0]
-
-    def finish(slot):
-        """complete the exchange that last used `slot`; rank 0 writes that frame"""
-        if comm is not None:                                         # RCCL calls were queued on `stream`: already ordered
-            if rank == 0 and ex.pending_frame[slot]:
-                t.stitch_tiles(ex.gathered[slot].data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, stream)
-            ex.pending_frame[slot] = False
-            return
-        g = ex.finish(slot)
-        if rank == 0 and g is not None and ex.pending_frame[slot]:
-            if args.rehearse:
-                dev_gathered.copy_(g)
-                g = dev_gathered
-            t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, stream)
-        ex.pending_frame[slot] = False
+    # N > 1: the exchange and rank 0's stitch run on a stream of their own, ordered by events -- frame k travels and is stitched
+    # (an HBM-bound copy of the whole frame) while frame k + 1 is being drawn on the render stream; a slot's next render waits for
+    # the event that says its previous frame has left it.  (Rehearsal: host copies between the steps, no overlap to speak of.)
+    side = torch.cuda.Stream(dev) if ex is not None else None
+    ev_drawn = [torch.cuda.Event() for _ in range(depth)] if side is not None else None
+    ev_left = [torch.cuda.Event() for _ in range(depth)] if side is not None else None
 
     pose = [rank]
 
@@ -234,25 +234,38 @@ def main():
             return
         slot = frame_no[0] % depth
         frame_no[0] += 1
-        finish(slot)                                                 # frame k - depth: its slab buffers are about to be reused
+        if ex.pending_frame[slot]:
+            render_stream.wait_event(ev_left[slot])                  # frame k - depth has left the slot (sent; on rank 0 stitched)
         out = dev_local if args.rehearse else ex.output(slot)
         t.set_output_device(out.data_ptr())
         t.render(stream)
-        if comm is not None:
-            t.dist_gather_tiles(comm, 0, ex.gathered[slot].data_ptr() if rank == 0 else 0, ex.stride, stream)
-        else:
-            if args.rehearse:
-                torch.cuda.synchronize()
+        ev_drawn[slot].record(render_stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_drawn[slot])
+            if args.rehearse:                                        # the same steps with a hop through host memory (gloo)
+                side.synchronize()
                 ex.output(slot).copy_(out)
-            ex.start(slot)
+                ex.start(slot)
+                g = ex.finish(slot)
+                if rank == 0:
+                    dev_gathered.copy_(g)
+                    g = dev_gathered
+            elif comm is not None:                                   # RCCL through the C-ABI, queued on the side stream
+                t.dist_gather_tiles(comm, 0, ex.gathered[slot].data_ptr() if rank == 0 else 0, ex.stride, side.cuda_stream)
+                g = ex.gathered[slot]
+            else:                                                    # torch.distributed: the work waits for the side stream's state, and the side stream for the work
+                ex.start(slot)
+                g = ex.finish(slot)
+            if rank == 0:
+                t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, side.cuda_stream)
+            ev_left[slot].record(side)
         ex.pending_frame[slot] = True
         if args.serial:
-            finish(slot)
+            side.synchronize()
 
     def flush():
         if ex is not None:
-            for k in range(depth):
-                finish((frame_no[0] + k) % depth)                    # oldest first
+            side.synchronize()                                       # every frame queued so far is gathered and stitched
 
     if ex is not None:
         ex.pending_frame = [False] * depth
@@ -342,6 +355,11 @@ def main():
             single.render(stream)
             torch.cuda.synchronize()
             check = bool(torch.equal(got, image))
+            if not check:                                            # say where: which tiles, how far apart
+                d = (got.to(torch.int16) - image.to(torch.int16)).abs().amax(dim=2)
+                ys, xs = torch.nonzero(d, as_tuple=True)
+                tiles = sorted({(int(x) // 64, int(y) // 64) for x, y in zip(xs[:2000].tolist(), ys[:2000].tolist())})
+                print(f"bench.py --check: {int((d > 0).sum())} pixels differ (largest difference {int(d.max())} LSB); tiles (tx, ty): {tiles[:24]}", file=sys.stderr)
             single.close()
         if world > 1:
             dist.barrier()

@@ -12,7 +12,9 @@
  *     thread-local, NUL-terminated description of the last failure on the calling thread.
  *   - host buffers are caller-owned and only borrowed for the duration of the call; device
  *     buffers passed to *_device entry points are borrowed until replaced or the object dies.
- *   - `stream` arguments are `hipStream_t` passed as `void*`; NULL = the object's own stream.
+ *   - `stream` arguments are `hipStream_t` passed as `void*`; NULL = the object's own stream (a non-blocking stream of the context:
+ *     NOT the legacy default stream -- a host that orders its own work by "the default stream", whose raw handle is 0 in HIP and in
+ *     torch.cuda, must create an explicit stream and pass that, or synchronise with vf_terrain_sync).
  *     Calls on one handle are not re-entrant.  Rendering is asynchronous on the stream; the
  *     read_* entry points synchronise.
  *   - no CPU fallback exists: without a HIP device vf_ctx_create fails with VF_ERR_NO_DEVICE.
@@ -75,6 +77,14 @@ int vf_device_query(int device_ordinal, vf_device_info *out);
 int vf_ctx_create(int device_ordinal, vf_ctx **out);
 void vf_ctx_destroy(vf_ctx *ctx);
 int vf_ctx_device_info(const vf_ctx *ctx, vf_device_info *out);
+/* The context's own stream (what a NULL `stream` argument means), as a hipStream_t: for a host that wants to order its own work
+ * -- events, copies, collectives -- on the stream the frames are drawn on without creating one more (torch:
+ * torch.cuda.ExternalStream(handle)).  Streams are a scarce resource here: the HIP runtime maps them onto GPU_MAX_HW_QUEUES
+ * hardware queues (default 4) round-robin, a handle uses three (this one and two of its own for the next frame's plan and set-up
+ * pass), and two streams that land on one queue run their kernels one after the other -- the next frame's set-up then no longer
+ * hides under this frame's tile kernel (C4: 0.87 -> 0.99 ms per frame, measured).  A host with streams of its own should raise
+ * GPU_MAX_HW_QUEUES (environment, before the HIP runtime starts; bench.py sets 8). */
+int vf_ctx_stream(const vf_ctx *ctx, void **stream);
 
 /* ---- terrain object ---------------------------------------------------------------------- */
 /*

@@ -16,7 +16,7 @@ VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -
 
 # every symbol include/vf_hip.h declares (checked by tests/test_cabi_symbols.py)
 SYMBOLS = [
-    "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info",
+    "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info", "vf_ctx_stream",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
@@ -54,6 +54,7 @@ _PROTOS = {
     "vf_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "vf_ctx_destroy": (None, [_vp]),
     "vf_ctx_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
+    "vf_ctx_stream": (_i, [_vp, C.POINTER(_vp)]),
     "vf_terrain_create": (_i, [_vp, _u32, _u32, _u32, _vp, _i, C.POINTER(_vp)]),
     "vf_terrain_destroy": (None, [_vp]),
     "vf_terrain_set_uniforms": (_i, [_vp, _vp]),
@@ -160,6 +161,12 @@ class Terrain:
             self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+    def stream_handle(self):
+        """hipStream_t of the context's own stream (what stream=None means), e.g. for torch.cuda.ExternalStream."""
+        h = _vp()
+        self._check(self.lib.vf_ctx_stream(self.ctx, C.byref(h)))
+        return h.value
 
     def set_uniforms(self, u):
         u = np.ascontiguousarray(u, dtype=np.float32).reshape(44)

@@ -236,6 +236,13 @@ int vf_ctx_device_info(const vf_ctx *ctx, vf_device_info *out)
     return VF_OK;
 }
 
+int vf_ctx_stream(const vf_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return fail(VF_ERR_INVALID, "NULL argument");
+    *stream = (void *)ctx->stream;
+    return VF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 
 static uint32_t compute_local_rows(uint32_t H, uint32_t rank, uint32_t nranks, uint32_t band_h)
@@ -1379,8 +1386,11 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     if (stride_tiles < most) return fail(VF_ERR_INVALID, "stride_tiles is smaller than the largest shard");
     VF_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(k_stitch_tiles, dim3(ntx * nty), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
-                       ntx, nranks, skew, stride_tiles);
+    // persistent, about one small workgroup per CU (VF_STITCH_WGS overrides): it has to fit beside the next frame's tile kernel
+    uint32_t wgs = (uint32_t)std::max(1, ctx->prop.multiProcessorCount);
+    if (const char *e = std::getenv("VF_STITCH_WGS")) wgs = (uint32_t)std::max(1, std::atoi(e));
+    hipLaunchKernelGGL(k_stitch_tiles, dim3(std::min(ntx * nty, wgs)), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
+                       ntx, nty, nranks, skew, stride_tiles);
     VF_HIP_TRY(hipGetLastError());
     return VF_OK;
 }

@@ -1572,20 +1572,19 @@ next_item:
             VF_PH(1)
             if (live) {
                 ++my_blocks;
+#ifndef VF_PHASE_PROF   // (the phase build measures waits: a device-scope atomic per pair in the middle of one would be what it measures)
                 if (stats && lane == 0)                    // diagnostics: which blocks were drawn by at least one tile this frame
                     atomicOr(&stats[4u + 4u * (P.ntx * P.nty + kSplitBudget) + 2u * kPhaseSlots + (bidx >> 5)], 1u << (bidx & 31u));
+#endif
                 const uint32_t i0 = bx * kBlockCells, j0 = by * kBlockCells;
                 // ---- set-up stage, once per frame in k_block_setup: here the block's snapped vertices and alive masks are loads ----
                 const unsigned long long alive_e = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.x) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.y) << 32);
                 const unsigned long long alive_o = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.z) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)r_hi.w) << 32);
                 const uint32_t rflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_lo.z);
                 VF_PH(16)                                  // (diagnostics: the record is here)
+                VF_PH(17)                                  // (diagnostics: nothing in between -- what one time stamp costs)
                 sXY[wave][lane] = xa;
                 if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
-#ifdef VF_PHASE_PROF
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-                VF_PH(17)                                  // (diagnostics: the vertices are here and staged)
                 if (!COMPLETE && (rflags & kRecGeneric)) { if (lane == 0) s_redo = 1u; }   // rare: clipped / oversized -> the COMPLETE launch
                 // the alive primitives as a dense list: cell c's even primitive sits at popcount(alive_e below c), its odd one behind all
                 // the even ones -- every lane of the classification below then holds a primitive that can draw
@@ -2203,28 +2202,44 @@ __global__ __launch_bounds__(256) void k_png_filter(const uint32_t *__restrict__
 }
 
 // multi-GPU, tile shards: [nranks][stride_tiles][64][64] rank-major gather buffer -> (H, W) image.  Tile (tx, ty) belongs
-// to rank (tx + skew * ty) % nranks; a rank numbers its tiles row-major.  One workgroup per screen tile.
+// to rank (tx + skew * ty) % nranks; a rank numbers its tiles row-major.  Persistent: a few hundred workgroups walk the screen tiles
+// with a grid stride, 16 bytes per lane where the frame allows it.  Few workgroups on purpose: on rank 0 this copy of the whole frame
+// runs on a side stream BESIDE the next frame's tile kernel, whose 1024-thread workgroups need most of a CU to start -- a launch of
+// one workgroup per tile fills every CU's wave slots and holds them back until it has drained (a rank of eight, emulated: frame
+// period +80 us instead of the +35 the copy is worth).
 __global__ __launch_bounds__(256) void k_stitch_tiles(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t W, uint32_t H,
-                                                      uint32_t ntx, uint32_t nranks, uint32_t skew, uint32_t stride_tiles)
+                                                      uint32_t ntx, uint32_t nty, uint32_t nranks, uint32_t skew, uint32_t stride_tiles)
 {
     __shared__ uint32_t s_local;
-    const uint32_t tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
-    const uint32_t r = (tx + skew * ty) % nranks;
-    if (threadIdx.x == 0) {
-        uint32_t before = 0;                               // tiles of rank r in the rows above
-        for (uint32_t t = 0; t < ty; ++t) {
-            const uint32_t first = (r + nranks - (skew * t) % nranks) % nranks;
-            before += first < ntx ? (ntx - 1u - first) / nranks + 1u : 0u;
+    const bool wide = (W & 3u) == 0u && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0u;
+    for (uint32_t tile = blockIdx.x; tile < ntx * nty; tile += gridDim.x) {
+        const uint32_t tx = tile % ntx, ty = tile / ntx;
+        const uint32_t r = (tx + skew * ty) % nranks;
+        __syncthreads();                                   // (the previous tile's s_local has been read)
+        if (threadIdx.x == 0) {
+            uint32_t before = 0;                           // tiles of rank r in the rows above
+            for (uint32_t t = 0; t < ty; ++t) {
+                const uint32_t first = (r + nranks - (skew * t) % nranks) % nranks;
+                before += first < ntx ? (ntx - 1u - first) / nranks + 1u : 0u;
+            }
+            const uint32_t first = (r + nranks - (skew * ty) % nranks) % nranks;
+            s_local = before + (tx - first) / nranks;
         }
-        const uint32_t first = (r + nranks - (skew * ty) % nranks) % nranks;
-        s_local = before + (tx - first) / nranks;
-    }
-    __syncthreads();
-    const uint32_t *tile = src + ((size_t)r * stride_tiles + s_local) * (kTileW * kTileH);
-    const uint32_t x0 = tx * kTileW, y0 = ty * kTileH;
-    for (uint32_t k = threadIdx.x; k < (uint32_t)(kTileW * kTileH); k += 256) {
-        const uint32_t lx = k % kTileW, ly = k / kTileW;
-        if (x0 + lx < W && y0 + ly < H) dst[(size_t)(y0 + ly) * W + x0 + lx] = tile[k];
+        __syncthreads();
+        const uint32_t *tp = src + ((size_t)r * stride_tiles + s_local) * (kTileW * kTileH);
+        const uint32_t x0 = tx * kTileW, y0 = ty * kTileH;
+        if (wide && x0 + kTileW <= W) {                    // whole-width tile: 16 lanes x 16 bytes per row
+            const uint4 *t4 = reinterpret_cast<const uint4 *>(tp);
+            for (uint32_t k = threadIdx.x; k < (uint32_t)(kTileW / 4 * kTileH); k += 256) {
+                const uint32_t lq = k % (kTileW / 4), ly = k / (kTileW / 4);
+                if (y0 + ly < H) *reinterpret_cast<uint4 *>(dst + (size_t)(y0 + ly) * W + x0 + 4u * lq) = t4[k];
+            }
+        } else {
+            for (uint32_t k = threadIdx.x; k < (uint32_t)(kTileW * kTileH); k += 256) {
+                const uint32_t lx = k % kTileW, ly = k / kTileW;
+                if (x0 + lx < W && y0 + ly < H) dst[(size_t)(y0 + ly) * W + x0 + lx] = tp[k];
+            }
+        }
     }
 }
 
