@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--cabi-gather", action="store_true",
                     help="N>1: exchange through the library's own RCCL entry points (vf_dist_comm_init / vf_dist_gather_tiles) "
                          "instead of torch.distributed's point-to-point calls")
+    ap.add_argument("--root-stitch", action="store_true",
+                    help="N>1: every slab to rank 0, which stitches the whole frame (round 2's exchange) instead of all-to-all + one band "
+                         "stitched per rank + in-place band gather")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
                          "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
@@ -197,17 +200,24 @@ def main():
     depth = 1 if args.serial else 2
     share = 1.0
     ex = comm = None
+    banded = False
     if world == 1 or c5:
         t.set_output_device(image.data_ptr())                    # whole frames: render straight into the frame
     else:
         # rehearsal: same exchange code over gloo through host memory (the device slabs are copied out and back in)
-        ex = vdist.TileExchange(W, H, "cpu" if args.rehearse else dev, depth=depth)
+        # Default: the stitch is sharded like the rendering (all-to-all, every rank stitches one band, bands gathered in place) when the
+        # tile grid divides by the ranks; --root-stitch / --cabi-gather: every slab to rank 0, which stitches the whole frame.
+        banded = vdist.band_exchange_applies(W, H, world) and not args.root_stitch and not args.cabi_gather
+        xdev = "cpu" if args.rehearse else dev
+        ex = vdist.BandStitchExchange(W, H, xdev, depth=depth) if banded else vdist.TileExchange(W, H, xdev, depth=depth)
         t.set_tile_shard(rank, world, ex.skew)
         assert t.local_tiles() == len(vdist.tile_layout(W, H, rank, world, ex.skew))
         share = t.local_tiles() / float(((W + 63) // 64) * ((H + 63) // 64))
         if args.rehearse:
             dev_local = torch.zeros(ex.stride * vdist.TILE_WORDS, dtype=torch.int32, device=dev)
-            dev_gathered = torch.zeros((world, ex.stride * vdist.TILE_WORDS), dtype=torch.int32, device=dev) if rank == 0 else None
+            dev_gathered = torch.zeros((world, (ex.chunk_tiles if banded else ex.stride) * vdist.TILE_WORDS), dtype=torch.int32, device=dev) if (rank == 0 or banded) else None
+            dev_band = torch.zeros((ex.band_rows, W, 4), dtype=torch.uint8, device=dev) if banded else None
+            host_image = torch.zeros((H, W, 4), dtype=torch.uint8) if (banded and rank == 0) else None
         if args.cabi_gather and not args.rehearse:
             # an RCCL communicator of the library's own (vf_dist_comm_init); the 128-byte id travels over the host-side group
             uid = [t.dist_unique_id() if rank == 0 else None]
@@ -245,19 +255,31 @@ def main():
             if args.rehearse:                                        # the same steps with a hop through host memory (gloo)
                 side.synchronize()
                 ex.output(slot).copy_(out)
-                ex.start(slot)
-                g = ex.finish(slot)
+            if banded:
+                def stitch_band(recv, band, rows):                   # [ranks][chunk] tile slots -> the rows of this rank's band (the C-ABI's kernel)
+                    src, dst = (dev_gathered.copy_(recv), dev_band) if args.rehearse else (recv, band)
+                    t.stitch_tiles(src.data_ptr(), dst.data_ptr(), world, 0, ex.chunk_tiles, side.cuda_stream, height=rows)
+                    if args.rehearse:
+                        side.synchronize()
+                        band.copy_(dev_band)
+                ex.exchange(slot, stitch_band, host_image if args.rehearse else image)
+                if args.rehearse and rank == 0:
+                    image.copy_(host_image)
+            else:
+                if args.rehearse:
+                    ex.start(slot)
+                    g = ex.finish(slot)
+                    if rank == 0:
+                        dev_gathered.copy_(g)
+                        g = dev_gathered
+                elif comm is not None:                               # RCCL through the C-ABI, queued on the side stream
+                    t.dist_gather_tiles(comm, 0, ex.gathered[slot].data_ptr() if rank == 0 else 0, ex.stride, side.cuda_stream)
+                    g = ex.gathered[slot]
+                else:                                                # torch.distributed: the work waits for the side stream's state, and the side stream for the work
+                    ex.start(slot)
+                    g = ex.finish(slot)
                 if rank == 0:
-                    dev_gathered.copy_(g)
-                    g = dev_gathered
-            elif comm is not None:                                   # RCCL through the C-ABI, queued on the side stream
-                t.dist_gather_tiles(comm, 0, ex.gathered[slot].data_ptr() if rank == 0 else 0, ex.stride, side.cuda_stream)
-                g = ex.gathered[slot]
-            else:                                                    # torch.distributed: the work waits for the side stream's state, and the side stream for the work
-                ex.start(slot)
-                g = ex.finish(slot)
-            if rank == 0:
-                t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, side.cuda_stream)
+                    t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, side.cuda_stream)
             ev_left[slot].record(side)
         ex.pending_frame[slot] = True
         if args.serial:
@@ -483,8 +505,9 @@ def main():
             metric = "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})"
             workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
             par = ("1 GPU, whole frame" if world == 1 else
-                   f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), p2p gather to rank 0 "
-                   f"({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, "
+                   f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), " +
+                   ("all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
+                    f"p2p gather to rank 0 ({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, ") +
                    f"{'serial' if args.serial else 'double-buffered'}")
         out = {
             "metric": metric, "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

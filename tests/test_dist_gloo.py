@@ -152,3 +152,67 @@ def test_tile_layout_properties():
             assert max(sizes) - min(sizes) <= nty                 # balanced to within one tile per tile row
     assert vdist.default_skew(8) == 0 and vdist.default_skew(3) == 0 and vdist.default_skew(2) == 0
     assert len(vdist.tile_layout(4096, 4096, 3, 8, 3)) == 512
+
+
+# ---- tile shards stitched in parallel: all-to-all + one band per rank + in-place band gather (dist.BandStitchExchange) ----------
+def _band_worker(rank, world, port, W, H, G, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import oracle as O
+    from vulkan_forge_amd import dist as vdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = np.load(os.path.join(ROOT, "tests", "golden", "colormaps_rgba8.npz"))["viridis"]
+    u = O.default_uniforms(O.KIND_SCENE, W, H)
+    h = np.random.default_rng(5).random((24, 24), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+    full, _ = O.render_terrain(u, W, H, G, h, lut)                      # the pixels come from the oracle (no GPU in this tier)
+    assert vdist.band_exchange_applies(W, H, world)
+    ex = vdist.BandStitchExchange(W, H, "cpu", depth=2)
+    lay = vdist.tile_layout(W, H, rank, world, 0)
+    assert len(lay) == ex.stride
+
+    def stitch(recv, band, rows):                                       # what vf_stitch_tiles_device does for a frame of `rows` rows
+        img = band.numpy()
+        for r in range(world):
+            slab = recv[r].numpy().view(np.uint8).reshape(-1, 64, 64, 4)
+            for k, (tx, ty) in enumerate(vdist.tile_layout(W, rows, r, world, 0)):
+                img[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = slab[k]
+
+    image = torch.zeros((H, W, 4), dtype=torch.uint8) if rank == 0 else None
+    ok = True
+    for f in range(5):                                                  # frame f = the oracle frame xor f: slots must not mix frames
+        slot = f % 2
+        frame = full ^ np.uint8(f)
+        slab = np.zeros((ex.stride, 64, 64, 4), np.uint8)
+        for k, (tx, ty) in enumerate(lay):
+            slab[k] = frame[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64]
+        ex.output(slot).copy_(torch.from_numpy(slab.reshape(-1).view(np.int32)))
+        ex.exchange(slot, stitch, image)
+        if rank == 0:
+            ok = ok and bool(np.array_equal(image.numpy(), frame))
+    dist.barrier()
+    if rank == 0:
+        q.put(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 256, 128), (4, 256, 256)])
+def test_tile_shards_band_stitch_exchange(world, W, H):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, 32, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_band_exchange_applicability():
+    from vulkan_forge_amd import dist as vdist
+    assert vdist.band_exchange_applies(4096, 4096, 8) and vdist.band_exchange_applies(4096, 4096, 2) and vdist.band_exchange_applies(4096, 4096, 4)
+    assert not vdist.band_exchange_applies(1920, 1080, 8) and not vdist.band_exchange_applies(4096, 4096, 3) and not vdist.band_exchange_applies(200, 150, 2)

@@ -26,23 +26,28 @@ image = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
 render = torch.cuda.ExternalStream(t.stream_handle(), device=dev); torch.cuda.set_stream(render); side = torch.cuda.Stream(dev)     # (the library's own stream as torch's current one)
 drawn = [torch.cuda.Event() for _ in range(depth)]; left = [torch.cuda.Event() for _ in range(depth)]
 
+band_rows = H // N
+chunk = (H // 64 // N) * (W // 64 // N)
+band = torch.empty((band_rows, W, 4), dtype=torch.uint8, device=dev)
+
 def run(mode, frames):
     for k in range(frames):
         s = k % depth
-        if mode == "side" and k >= depth: render.wait_event(left[s])
+        if mode in ("side", "band") and k >= depth: render.wait_event(left[s])
         t.set_output_device(gathered[s][0].data_ptr())
         t.render(render.cuda_stream)
         if mode == "same":
             t.stitch_tiles(gathered[s].data_ptr(), image.data_ptr(), N, 0, stride, render.cuda_stream)
-        elif mode == "side":
+        elif mode in ("side", "band"):
             drawn[s].record(render)
             with torch.cuda.stream(side):
                 side.wait_event(drawn[s])
-                t.stitch_tiles(gathered[s].data_ptr(), image.data_ptr(), N, 0, stride, side.cuda_stream)
+                if mode == "side": t.stitch_tiles(gathered[s].data_ptr(), image.data_ptr(), N, 0, stride, side.cuda_stream)
+                else: t.stitch_tiles(gathered[s].data_ptr(), band.data_ptr(), N, 0, chunk, side.cuda_stream, height=band_rows)   # what EVERY rank does in dist.BandStitchExchange
                 left[s].record(side)
     torch.cuda.synchronize()
 
-for mode in ("none", "same", "side", "none", "same", "side"):
+for mode in ("none", "same", "side", "band", "none", "same", "side", "band"):
     run(mode, 40)
     t0 = time.perf_counter(); run(mode, 200); dt = (time.perf_counter() - t0) / 200 * 1e3
     print(f"rank 0 of {N}, {cam}: stitch {mode:5s}: frame period {dt:.4f} ms", flush=True)

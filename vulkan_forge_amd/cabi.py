@@ -207,9 +207,10 @@ class Terrain:
             self._check(self.lib.vf_terrain_read_tiles(self.t, out.ctypes.data, 0, n))
         return out
 
-    def stitch_tiles(self, gathered_dptr, image_dptr, nranks, skew, stride_tiles, stream=None):
-        self._check(self.lib.vf_stitch_tiles_device(self.ctx, _vp(gathered_dptr), _vp(image_dptr), self.W, self.H, nranks, skew,
-                                                    stride_tiles, _vp(stream or 0)))
+    def stitch_tiles(self, gathered_dptr, image_dptr, nranks, skew, stride_tiles, stream=None, height=None):
+        """`height`: stitch a frame of that many rows instead of the handle's (a band of the frame: dist.BandStitchExchange)."""
+        self._check(self.lib.vf_stitch_tiles_device(self.ctx, _vp(gathered_dptr), _vp(image_dptr), self.W, self.H if height is None else int(height),
+                                                    nranks, skew, stride_tiles, _vp(stream or 0)))
 
     # ---- RCCL exchange through the C-ABI (include/vf_hip.h, "multi-GPU exchange over RCCL") ----
     def dist_unique_id(self):

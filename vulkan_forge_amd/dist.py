@@ -144,3 +144,66 @@ class TileExchange:
                 w.wait()
             self.pending[slot] = None
         return self.gathered[slot]
+
+
+# ---- tile shards, stitched in parallel: all-to-all + per-rank band stitch + in-place band gather ------------------------
+def band_exchange_applies(width: int, height: int, nranks: int) -> bool:
+    """`BandStitchExchange` needs column stripes that divide evenly and bands of whole tile rows: ntx and nty multiples of nranks."""
+    ntx, nty = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    return nranks >= 1 and width % TILE == 0 and height % TILE == 0 and ntx % nranks == 0 and nty % nranks == 0
+
+
+class BandStitchExchange:
+    """Tile shards (column stripes, skew 0) to a row-major frame on rank `dst` WITHOUT a whole-frame stitch on that rank.
+
+    `TileExchange` ends in `vf_stitch_tiles_device` on rank `dst`: a copy of the whole frame (128 MiB of HBM traffic at
+    4096 x 4096) that only that rank pays -- +38 us on a rank of eight whose frame takes 0.22 ms, wherever the copy is queued
+    (tools/exp_rank0_stitch.py).  Here the stitch is sharded like the rendering:
+
+      1. all-to-all: the frame is cut into `nranks` horizontal bands of whole tile rows; a rank's slab (its tiles, row-major by
+         (ty, tx)) holds the tiles of band b contiguously, and sends that chunk to rank b -- an eighth of a slab per peer, every
+         xGMI link busy in both directions, nobody's links a hot spot;
+      2. every rank stitches ITS band (a frame of H / nranks rows, the same kernel): 1 / nranks of the copy each;
+      3. the bands are contiguous slabs of the final image: rank `dst` receives them in place (`dist.gather` into views of the
+         image), no further pass.
+
+    Double-buffered like `TileExchange`; `stitch(recv, band_image, band_rows)` is the caller's (the C-ABI's stitch kernel on the
+    GPU, NumPy in the CPU tests).  Works on CUDA tensors with nccl (RCCL) and on CPU tensors with gloo."""
+
+    def __init__(self, width, height, device, depth=2, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group, self.dst, self.torch = dist, group, dst, torch
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if not band_exchange_applies(width, height, self.world):
+            raise ValueError("BandStitchExchange needs tile columns and tile rows that divide by the number of ranks")
+        self.W, self.H, self.skew, self.depth = width, height, 0, depth
+        ntx, nty = width // TILE, height // TILE
+        self.band_rows = height // self.world                         # pixel rows per band
+        self.chunk_tiles = (nty // self.world) * (ntx // self.world)  # tiles one rank holds of one band
+        self.stride = self.chunk_tiles * self.world                   # tiles per rank (= its slab)
+        words = self.stride * TILE_WORDS
+        self.local = [torch.zeros(words, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.recv = [torch.zeros((self.world, self.chunk_tiles * TILE_WORDS), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.band = [torch.zeros((self.band_rows, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+
+    def output(self, slot):
+        return self.local[slot]
+
+    def exchange(self, slot, stitch, image):
+        """Frame in `output(slot)` -> rows of `image` ((H, W, 4) uint8, used on `dst`).  Ordered on the caller's current stream
+        (the collectives make it wait); returns when everything is queued (GPU) or done (CPU)."""
+        dist = self.dist
+        if self.world > 1:
+            dist.all_to_all_single(self.recv[slot].view(-1), self.local[slot], group=self.group)
+        else:
+            self.recv[slot].view(-1).copy_(self.local[slot])
+        stitch(self.recv[slot], self.band[slot], self.band_rows)      # [nranks][chunk_tiles] tile slots -> band_rows x W pixels
+        b = self.band_rows
+        if self.world == 1:
+            image.copy_(self.band[slot])
+        elif self.rank == self.dst:
+            dist.gather(self.band[slot], gather_list=[image[r * b:(r + 1) * b] for r in range(self.world)], dst=self.dst, group=self.group)
+        else:
+            dist.gather(self.band[slot], dst=self.dst, group=self.group)
