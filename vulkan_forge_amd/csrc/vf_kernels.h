@@ -322,6 +322,18 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
     return v;
 }
 
+// inclusive running maximum across the wave (values >= 0), the same DPP ladder
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
+{
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
 __global__ __launch_bounds__(kSetupThreads) void k_block_setup(FrameParams P, const float *__restrict__ hblk,
                                                                const PixelBox *__restrict__ cons_boxes, VertexRec *__restrict__ vtx,
                                                                BlockRec *__restrict__ recs, ulonglong2 *__restrict__ gen,
@@ -578,7 +590,8 @@ __device__ __noinline__ void raster_generic(const GVert v[3], float hw, float hh
 
 // Tile-dependent part of the classification of a primitive k_block_setup found alive (no clipping needed, front-facing, a pixel
 // centre of the target inside its bounding box): does it hold a pixel centre of this tile that is still open?
-__device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2 VF_RC_ARG)
+// `lines`: how many lines raster_fast will walk for it (the shorter side of its box inside the tile).
+__device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, uint32_t &lines VF_RC_ARG)
 {
     const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
     const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
@@ -587,6 +600,7 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
     if (px0 > px1 || py0 > py1) return false;             // no pixel centre of the tile inside the bbox
     // occlusion: every candidate pixel already final
     const bool cols = (px1 - px0) <= (py1 - py0);
+    lines = (uint32_t)(min(px1 - px0, py1 - py0) + 1);
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
     const int32_t o0 = cols ? px0 - T.px_lo : py0 - T.py_lo, o1 = cols ? px1 - T.px_lo : py1 - T.py_lo;
     const uint64_t seg = cols ? bit_range(py0 - T.py_lo, py1 - T.py_lo) : bit_range(px0 - T.px_lo, px1 - T.px_lo);
@@ -1152,8 +1166,19 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             if (mean && px_hi - px_lo + 1 == kTileW) {
                 const uint32_t q = seen / mean;
 #if VF_SLICES
+#ifndef VF_SLICE_POLICY
+#define VF_SLICE_POLICY 0
+#endif
+#if VF_SLICE_POLICY == 1      // depth slices first (2, then 4), column strips beyond
+                lgs = q >= 4u ? 2u : q >= 2u ? 1u : 0u;
+                lg = q >= 32u ? 3u : q >= 16u ? 2u : q >= 8u ? 1u : 0u;
+#elif VF_SLICE_POLICY == 2    // two depth slices first, then strips, then four slices
+                lgs = q >= 32u ? 2u : q >= 2u ? 1u : 0u;
+                lg = q >= 16u ? 3u : q >= 8u ? 2u : q >= 4u ? 1u : 0u;
+#else
                 lg = q >= 64u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
                 lgs = q >= 32u ? 2u : q >= 16u ? 1u : 0u;
+#endif
 #else
                 lg = q >= 16u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
 #endif
@@ -1302,6 +1327,18 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ int2 sXY[kWaves][kNV];                      // per wave: snapped vertices of the current block (from k_block_setup)
     __shared__ uint8_t sC[kWaves][2 * kBlockCells * kBlockCells];   // per wave: the block's alive primitives (cell << 1 | odd), compacted
     __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: those of them that survive against this tile
+#ifndef VF_BALANCE
+#define VF_BALANCE 1
+#endif
+#ifndef VF_WIDE_LINES
+#define VF_WIDE_LINES 20
+#endif
+#ifndef VF_BAL_GAIN
+#define VF_BAL_GAIN 2
+#endif
+#if VF_BALANCE
+    __shared__ uint8_t sL[kWaves][2 * kBlockCells * kBlockCells];   // per wave: ... and how many lines each of them has inside the tile
+#endif
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
     __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
     __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
@@ -1345,6 +1382,12 @@ next_item:
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[item_idx].x;
+#ifdef VF_TILE_PRIO      // experiment: the frame's heaviest items (the first VF_TILE_PRIO_ITEMS of the sorted list) win the issue arbitration
+#ifndef VF_TILE_PRIO_ITEMS
+#define VF_TILE_PRIO_ITEMS 0xFFFFFFFFu
+#endif
+    if (!COMPLETE) { if (item_idx < (uint32_t)VF_TILE_PRIO_ITEMS) __builtin_amdgcn_s_setprio(VF_TILE_PRIO); else __builtin_amdgcn_s_setprio(0); }
+#endif
     const uint32_t tile = work_tile(item);
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
@@ -1608,19 +1651,29 @@ next_item:
                 }
                 // ---- pass A: lane = alive primitive: bbox against the tile, occlusion; compact the survivors (ballot + prefix popcount) ----
                 uint32_t nsurv = 0;
+                bool any_wide = false;                     // a survivor with more than kWideLines lines: only then is the lane dealing below looked at
                 for (uint32_t k0 = 0; k0 < n_alive; k0 += 64u) {
                     const uint32_t k = k0 + lane;
                     bool keep = false;
-                    uint32_t code = 0;
+                    uint32_t code = 0, nlines = 0;
                     if (k < n_alive) {
                         code = sC[wave][k];
                         const uint32_t cell = code >> 1, odd = code & 1u;
                         const uint32_t va = (cell >> 3) * kBlockVerts + (cell & 7u);
                         const int2 q0 = sXY[wave][odd ? va + 1u : va], q1 = sXY[wave][va + kBlockVerts], q2 = sXY[wave][odd ? va + kBlockVerts + 1u : va + 1u];
-                        keep = classify_alive(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y VF_RC(, RC));
+                        keep = classify_alive(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, nlines VF_RC(, RC));
                     }
                     const unsigned long long m = __ballot(keep);
-                    if (keep) sS[wave][nsurv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)code;
+#if VF_BALANCE
+                    any_wide = any_wide || __ballot(keep && nlines > (uint32_t)VF_WIDE_LINES) != 0ull;
+#endif
+                    if (keep) {
+                        const uint32_t at = nsurv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        sS[wave][at] = (uint8_t)code;
+#if VF_BALANCE
+                        sL[wave][at] = (uint8_t)nlines;
+#endif
+                    }
                     nsurv += (uint32_t)__popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1633,18 +1686,61 @@ next_item:
                     const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_per[min(nsurv, 64u)]);
                     const uint32_t per = pe & 0x7Fu, group = pe >> 24;          // group = survivors per round = 64 / per
                     const uint32_t q = (lane * ((pe >> 7) & 0x1FFFFu)) >> 16, sub = lane - q * per;
-                    for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {
+#if VF_BALANCE
+                    // Even shares leave the wave waiting for its widest triangle (6.9 trips through the line loop per pair at C4's default
+                    // camera where the lines would fill 3.5; 27 against 13 with the fill camera).  When that costs two trips or more, the
+                    // lanes are dealt in proportion to the line counts instead: chunks of C = ceil(lines / (64 - survivors)) lines,
+                    // survivor k gets ceil(L_k / C) lanes (at most 64 in all), found by a running maximum over the lanes.
+                    bool balanced = false;
+                    uint32_t b_mine = 0, b_used = 0;                               // balanced: code | first lane << 8 | lanes << 16 of this lane's survivor
+                    if (any_wide && nsurv > 1u && nsurv <= 56u) {                  // (uniform)
+                        const uint32_t Lk = lane < nsurv ? (uint32_t)sL[wave][lane] : 0u;
+                        const uint32_t incL = wave_scan_add(Lk), maxL = wave_scan_max(Lk);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incL, 63), widest = (uint32_t)__builtin_amdgcn_readlane((int)maxL, 63);
+                        const uint32_t spare = 64u - nsurv;
+                        // (uniform integer divisions by small numbers: the +0.5 keeps the 1-ulp reciprocal on the right side of exact quotients)
+                        uint32_t C = (uint32_t)(((float)(total + spare - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)spare));      // always fits: sum of ceil(L / C) <= 64
+                        {   // rounding up costs half a lane per survivor on average, not a whole one: try the chunk size that assumes so, keep it if it fits
+                            const uint32_t spare2 = 64u - (nsurv >> 1) - 2u;
+                            const uint32_t C2 = (uint32_t)(((float)(total + spare2 - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)spare2));
+                            const uint32_t m2 = lane < nsurv ? (uint32_t)(((float)(Lk + C2 - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)C2)) : 0u;
+                            if ((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(m2), 63) <= 64u) C = C2;
+                        }
+                        const uint32_t trips_now = (uint32_t)(((float)(widest + per - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)per));
+                        if (__builtin_amdgcn_readfirstlane((int)(trips_now >= C + (uint32_t)VF_BAL_GAIN ? 1u : 0u))) {     // (the same in every lane: keep the branch scalar)
+                            balanced = true;
+                            const uint32_t mk = lane < nsurv ? (uint32_t)(((float)(Lk + C - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)C)) : 0u;   // lanes for survivor `lane`
+                            const uint32_t inc = wave_scan_add(mk), start = inc - mk;
+                            // owner of lane l = the last survivor whose first lane is <= l: marks at the first lanes, running maximum
+                            sC[wave][lane] = 0;                                    // (the alive list is done with: its bytes carry the marks)
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < nsurv) sC[wave][start] = (uint8_t)(lane + 1u);
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t owner = wave_scan_max((uint32_t)sC[wave][lane]) - 1u;
+                            const uint32_t packed = (uint32_t)sS[wave][min(lane, nsurv - 1u)] | (start << 8) | (mk << 16);   // of survivor `lane`
+                            b_mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)packed);
+                            b_used = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                        }
+                    }
+#else
+                    constexpr bool balanced = false;
+                    constexpr uint32_t b_mine = 0, b_used = 0;
+#endif
+                    for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {      // (balanced: one round)
                         VF_RC(if (lane == 0) rc_iters++;)
                         const uint32_t sidx = sbase + q;
-                        if (q < group && sidx < nsurv) {
-                            const uint32_t code = sS[wave][sidx];
+                        const bool act = balanced ? lane < b_used : (q < group && sidx < nsurv);
+                        if (act) {
+                            const uint32_t code = balanced ? (b_mine & 0xFFu) : (uint32_t)sS[wave][sidx];
+                            const uint32_t my_sub = balanced ? lane - ((b_mine >> 8) & 0xFFu) : sub, my_n = balanced ? b_mine >> 16 : per;
                             const uint32_t cell = code >> 1, odd = code & 1u;
                             const uint32_t lj = cell >> 3, li = cell & 7u;
                             const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)sub, (int32_t)per VF_RC(, RC));
+                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)my_sub, (int32_t)my_n VF_RC(, RC));
                         }
+                        if (balanced) break;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1907,9 +2003,6 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, SetupView V, con
 // pixel passes its 256 words through LDS (row pitch 20 words: 16-byte aligned rows, at most two-way bank conflicts) and shades the four
 // 8 x 8 quarters of its area one pixel per lane, as above.  Background regions (84 % of C4's default frame) cost one 16-byte
 // load and one 16-byte store per lane; covered ones keep the 2-D locality that the L1 needs.
-#ifndef VF_RESOLVE_UNROLL
-#define VF_RESOLVE_UNROLL 1
-#endif
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_resolve4(FrameParams P, SetupView V, const float *__restrict__ lut_linear,
                                                   const float *__restrict__ thresh, const uint4 *__restrict__ vis,
@@ -1968,7 +2061,7 @@ __global__ __launch_bounds__(256) void k_resolve4(FrameParams P, SetupView V, co
             *reinterpret_cast<uint4 *>(mine4) = id;
             __builtin_amdgcn_wave_barrier();               // LDS operations of one wave complete in order; keep the compiler from reordering
             const int32_t ax = (int32_t)((rx * 8u + (wv & 1u) * 4u) * 4u), ay = (int32_t)(ry * 32u + (wv >> 1) * 16u);   // the wave's area
-#pragma unroll VF_RESOLVE_UNROLL
+#pragma unroll 1
             for (uint32_t t8 = 0; t8 < 4u; ++t8) {         // its four 8 x 8 quarters, one pixel per lane
                 const uint32_t sx = (t8 & 1u) * 8u + (lane & 7u), sy = (t8 >> 1) * 8u + (lane >> 3);
                 uint32_t *const w = sw + sy * kPitch + sx;
