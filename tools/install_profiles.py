@@ -51,9 +51,9 @@ open(os.path.join(P, f"{prefix}_bench.json"), "w").write(last_json_line(os.path.
 open(os.path.join(P, f"{prefix}_bench_c5.json"), "w").write(last_json_line(os.path.join(G, "bench_c5.json")) + "\n")
 open(os.path.join(P, f"{prefix}_rehearse_4ranks.json"), "w").write(last_json_line(os.path.join(G, "rehearse_4ranks.json")) + "\n")
 copy("kernel_stats.csv", "kernel_stats.csv")
-for n in ("fetch_default", "write_default", "frag_fetch", "frag_write"):
+for n in ("fetch_default", "write_default", "frag_fetch_default", "frag_write_default", "frag_fetch_fill", "frag_write_fill", "frag_l1_default", "frag_l1_fill"):
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
-for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log"):
+for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log", "rank0_stitch.log", "cold.log", "fragment.log", "parity_soak.log"):
     copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
 
@@ -66,7 +66,7 @@ for n in ("sq_a", "sq_b"):
     for (kern, ctr), v in sorted(pk.items()):
         if "k_tile" in kern or "k_block_setup" in kern:
             lines.append(f"  {kern:26s} {ctr:26s} {v:16.0f}")
-        if kern == "vf::k_tile<false, false>":
+        if kern.startswith("vf::k_tile<false, false"):
             sq[ctr] = v
 open(os.path.join(P, f"{prefix}_sq_counters.txt"), "w").write("\n".join(lines) + "\n")
 
@@ -106,13 +106,24 @@ for cam in ("default", "fill"):
         }
     data[f"4096x4096_g4096_{cam}_n1"] = entry
 
-# ---- the fragment stage on its own (k_resolve): measured traffic next to the algorithmic bytes ----------------------------
-ff = per_kernel(os.path.join(G, "pmc_frag_fetch.csv"))
-fw = per_kernel(os.path.join(G, "pmc_frag_write.csv"))
-frag = {k[0]: v for k, v in ff.items() if "k_resolve" in k[0]}
-fragw = {k[0]: v for k, v in fw.items() if "k_resolve" in k[0]}
-data["fragment_stage_k_resolve"] = {"tag": prefix, "lib_sha256": lib_hash, "FETCH_SIZE_KiB_avg_over_both_cameras": frag, "WRITE_SIZE_KiB_avg_over_both_cameras": fragw,
-                                    "note": "tools/exp_fragment.py: default camera first, then fill; per-dispatch values in profiles/%s_pmc_frag_*.csv" % prefix}
+# ---- the fragment stage on its own (k_resolve4): measured traffic per camera next to the algorithmic bytes -----------------
+for cam in ("default", "fill"):
+    ff = per_kernel(os.path.join(G, f"pmc_frag_fetch_{cam}.csv"))
+    fw = per_kernel(os.path.join(G, f"pmc_frag_write_{cam}.csv"))
+    l1 = per_kernel(os.path.join(G, f"pmc_frag_l1_{cam}.csv"))
+    fetch = sum(v for (k, c), v in ff.items() if "k_resolve" in k and c == "FETCH_SIZE")
+    write = sum(v for (k, c), v in fw.items() if "k_resolve" in k and c == "WRITE_SIZE")
+    c = {cn: v for (k, cn), v in l1.items() if "k_resolve" in k}
+    data[f"4096x4096_g4096_frag_{cam}"] = {
+        "tag": prefix, "lib_sha256": lib_hash, "kernel": "k_resolve4 (vf_terrain_debug_fragment_stage)",
+        "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+        "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "hbm_bytes_per_launch_fetch_uncorrected": int((fetch + write) * 1024),
+        "algorithmic_bytes": 201326592,
+        "l1": {"accesses": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "requests_to_l2": c.get("TCP_TCC_READ_REQ_sum"), "l2_hits": c.get("TCC_HIT_sum"),
+               "l2_misses": c.get("TCC_MISS_sum"),
+               "l1_stalled_on_l2_frac": (c["TCP_PENDING_STALL_CYCLES_sum"] / 256.0) / (c["GRBM_GUI_ACTIVE"] / 8.0) if c.get("GRBM_GUI_ACTIVE") else None},
+        "note": "averages per launch (tools/exp_fragment.py: one warm-up + 10 timed launches); FETCH doubled per the guide's gfx950 correction in hbm_bytes_per_launch"}
+data.pop("fragment_stage_k_resolve", None)
 json.dump(data, open(path, "w"), indent=1)
 b = json.loads(open(os.path.join(P, f"{prefix}_bench.json")).read())
 print("bench:", round(b["value"]), "Mpix/s", round(b["ms_per_step"], 4), "ms; kernel", round(b["roofline"]["kernel_ms"], 4), "ms; hbm frac", round(100 * b["roofline"]["frac"], 2),

@@ -4,7 +4,7 @@
 out=gpurun_out/$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/prof" -o run -- python3 "$GRAFT_REPO_ROOT/tools/exp_rank_trace.py" "$@" > "$GRAFT_REPO_ROOT/$out/rank.log" 2> "$GRAFT_REPO_ROOT/$out/rank.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/prof" -o run -- python3 "$GRAFT_REPO_ROOT/tools/exp_rank_trace.py" "$@" > "$GRAFT_REPO_ROOT/$out/rank.log" 2> "$GRAFT_REPO_ROOT/$out/rank.err"
 cd "$GRAFT_REPO_ROOT"
 python3 - "$out/prof/run_kernel_trace.csv" <<'PY'
 import csv, sys, collections
@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last 6 frames: print the timeline relative to the start of a frame's main tile kernel
 names = [(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vf::", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-clears = [i for i, n in enumerate(names) if n[0] == "k_tile<false, false>"]
+clears = [i for i, n in enumerate(names) if n[0].startswith("k_tile<false, false")]
 if len(clears) > 8:
     t0 = names[clears[-6]][1]
     for n, s, e in names[clears[-6]:clears[-3]]:

@@ -11,11 +11,11 @@ sha256sum vulkan_forge_amd/libvf_hip.so | cut -d' ' -f1 > "$out/lib_sha256.txt"
 echo "== pytest -m gpu"; timeout -k 10 900 python -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1; tail -2 "$out/pytest_gpu.log"
 echo "== bench (C4)"; timeout -k 10 600 python bench.py --steps 20 --warmup 3 --check > "$out/bench.json" 2> "$out/bench.err" || exit 1
 echo "== bench (C5)"; timeout -k 10 600 python bench.py --workload c5 --steps 64 --warmup 8 > "$out/bench_c5.json" 2> "$out/bench_c5.err" || exit 1
-echo "== kernel trace"; (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/trace" -o run -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra > "$R/$out/bench_traced.json" 2> "$R/$out/trace.err") || exit 1
+echo "== kernel trace"; (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/trace" -o run -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra > "$R/$out/bench_traced.json" 2> "$R/$out/trace.err") || exit 1
 cp "$(find $out/trace -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
-pmc() {   # pmc <name> "<counters>" <program args...>
+pmc() {   # pmc <name> "<counters>" <program args...>      (every pass under a timeout: a counter set that cannot be collected hangs the run)
   local name=$1 ctr=$2; shift; shift
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --output-format csv -d "$R/$out/pmc_$name" -o run -- python3 "$@" > "$R/$out/pmc_$name.json" 2> "$R/$out/pmc_$name.err") || return 1
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d "$R/$out/pmc_$name" -o run -- python3 "$@" > "$R/$out/pmc_$name.json" 2> "$R/$out/pmc_$name.err") || return 1
   cp "$(find $out/pmc_$name -name '*counter_collection.csv' | head -1)" "$out/pmc_$name.csv"
 }
 B="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra"
@@ -26,11 +26,18 @@ pmc fetch_fill "FETCH_SIZE" $B --camera fill || exit 1
 pmc write_fill "WRITE_SIZE" $B --camera fill || exit 1
 pmc sq_a "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS" $B || exit 1
 pmc sq_b "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" $B || exit 1
-pmc frag_fetch "FETCH_SIZE" "$R/tools/exp_fragment.py" || exit 1
-pmc frag_write "WRITE_SIZE" "$R/tools/exp_fragment.py" || exit 1
+for cam in default fill; do      # the fragment stage alone (k_resolve4), one camera per pass
+  pmc frag_fetch_$cam "FETCH_SIZE" "$R/tools/exp_fragment.py" $cam || exit 1
+  pmc frag_write_$cam "WRITE_SIZE" "$R/tools/exp_fragment.py" $cam || exit 1
+  pmc frag_l1_$cam "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" "$R/tools/exp_fragment.py" $cam || exit 1
+done
+echo "== fragment stage"; timeout -k 10 120 python tools/exp_fragment.py both > "$out/fragment.log" 2>&1; VF_RESOLVE_PER_PIXEL=1 timeout -k 10 120 python tools/exp_fragment.py both >> "$out/fragment.log" 2>&1; timeout -k 10 120 python tools/exp_fragment.py both exact >> "$out/fragment.log" 2>&1; cat "$out/fragment.log"
 echo "== ranks"; timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0 4:0 8:0 8:3 > "$out/ranks.log" 2>&1; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0 4:0 8:0 8:3 >> "$out/ranks.log" 2>&1; cat "$out/ranks.log"
 tools/prof_rank.sh $tag/rank_trace 2 8 0 > "$out/rank_timeline.log" 2>&1; tail -3 "$out/rank_timeline.log"
 timeout -k 10 300 python tools/exp_toptiles.py > "$out/top_items.log" 2>&1
 timeout -k 10 300 python tools/exp_rank_frames.py 2 8 > "$out/rank_frames.log" 2>&1; grep period "$out/rank_frames.log"
+echo "== rank 0's stitch"; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 default > "$out/rank0_stitch.log" 2>&1; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 fill >> "$out/rank0_stitch.log" 2>&1; grep period "$out/rank0_stitch.log" | tail -8
+echo "== first frames"; timeout -k 10 200 python tools/exp_cold.py default > "$out/cold.log" 2>&1; timeout -k 10 200 python tools/exp_cold.py fill >> "$out/cold.log" 2>&1; grep rep "$out/cold.log"
 echo "== rehearsal"; timeout -k 10 600 python bench.py --gpus 4 --rehearse --check --no-cpu-baseline --steps 5 > "$out/rehearse_4ranks.json" 2> "$out/rehearse_4ranks.err"; tail -c 300 "$out/rehearse_4ranks.json"
+echo "== soak"; timeout -k 10 400 python tests/soak_parity.py 400000 100000 300 > "$out/parity_soak.log" 2>&1; tail -1 "$out/parity_soak.log"
 echo "== done"
