@@ -1594,8 +1594,11 @@ next_item:
             // vertices are requested together, before the box decides whether the block is still worth drawing -- a dependent
             // second trip costs a wave more than the vertices of the blocks that turn out culled.
             const uint32_t bidx = by * P.nb + bx;
-            const uint4 *recw = reinterpret_cast<const uint4 *>(V.recs + bidx);     // (wave-uniform address)
-            const uint4 r_lo = recw[0], r_hi = recw[1];            // box (2 words), flags, count | alive_even, alive_odd
+            // (wave-uniform address, data the set-up pass wrote before this launch: read through the scalar cache into scalar registers --
+            //  the box arithmetic of the late cull below then runs on the scalar unit)
+            typedef uint32_t __attribute__((ext_vector_type(8))) rec_words;
+            const rec_words rw = *(const __attribute__((address_space(4))) rec_words *)(uintptr_t)(V.recs + bidx);
+            const uint4 r_lo = make_uint4(rw[0], rw[1], rw[2], rw[3]), r_hi = make_uint4(rw[4], rw[5], rw[6], rw[7]);   // box (2 words), flags, count | alive_even, alive_odd
             const uint4 *vsrc = reinterpret_cast<const uint4 *>(V.vtx + (size_t)bidx * kBlockStride);
             const uint4 va4 = vsrc[lane];
             uint4 vb4 = make_uint4(0u, 0u, 0u, 0u);
