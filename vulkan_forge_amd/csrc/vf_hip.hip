@@ -426,6 +426,12 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
     t->d_height = t->d_height_own;
     VF_HIP_TRY(hipMemcpyAsync(t->d_height_own, host_height, bytes, hipMemcpyHostToDevice, t->ctx->stream));
     int rc = set_height_common(t, tw, th);
+    if (rc == VF_OK) {
+        // the per-block height cache and bounds depend on the texture alone: built here, behind the upload, not by the first frame
+        // (a texture handed over in device memory may still be written by the caller's stream: that one is cached by the next frame)
+        hipLaunchKernelGGL(k_height_blocks, dim3(t->nblocks), dim3(64), 0, t->ctx->stream, t->n, t->nb, t->tw, axis(t), t->d_height, t->d_hblk, t->d_bounds);
+        if (hipGetLastError() == hipSuccess) t->bounds_dirty = false;
+    }
     VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));   // host buffer is only borrowed for this call
     return rc;
 }
