@@ -526,7 +526,7 @@ def main():
             out["ms_per_pose"] = dt / args.steps * 1e3               # per rank: one pose per step
         if cold:
             out["cold_frame_ms"] = cold[0]
-            out["cold_frames_ms"] = {"first (builds the height cache, no feedback)": cold[0], "second (first frame's feedback)": cold[1], "third": cold[2]}
+            out["cold_frames_ms"] = {"first (planned from the static estimate: no feedback yet)": cold[0], "second (first frame's feedback)": cold[1], "third": cold[2]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
         if args.rehearse:
