@@ -58,7 +58,11 @@ def parse():
     ap.add_argument("--camera", choices=["default", "fill"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other camera, fragment stage, cold frame)")
-    ap.add_argument("--check", action="store_true", help="after timing, compare the gathered frame with a single-rank render")
+    ap.add_argument("--check", action="store_true", help="after timing, compare the gathered frame with a single-rank render "
+                                                         "(always done at N > 1: a scaling number is only printed for a frame that was proven)")
+    ap.add_argument("--no-api-latency", action="store_true",
+                    help="skip the end-to-end timing of the drop-in API (TerrainSpike / Scene render_png and render_rgba incl. read-back and PNG "
+                         "encode at C2, C3 and C4; a few hundred ms)")
     ap.add_argument("--serial", action="store_true", help="N>1: finish each frame's exchange before rendering the next (no overlap)")
     ap.add_argument("--cabi-gather", action="store_true",
                     help="N>1: exchange through the library's own RCCL entry points (vf_dist_comm_init / vf_dist_gather_tiles) "
@@ -200,14 +204,15 @@ def main():
     depth = 1 if args.serial else 2
     share = 1.0
     ex = comm = None
-    banded = False
+    banded = cabi_bands = False
     if world == 1 or c5:
         t.set_output_device(image.data_ptr())                    # whole frames: render straight into the frame
     else:
         # rehearsal: same exchange code over gloo through host memory (the device slabs are copied out and back in)
         # Default: the stitch is sharded like the rendering (all-to-all, every rank stitches one band, bands gathered in place) when the
         # tile grid divides by the ranks; --root-stitch / --cabi-gather: every slab to rank 0, which stitches the whole frame.
-        banded = vdist.band_exchange_applies(W, H, world) and not args.root_stitch and not args.cabi_gather
+        banded = vdist.band_exchange_applies(W, H, world) and not args.root_stitch
+        cabi_bands = banded and args.cabi_gather and not args.rehearse     # the same exchange through the library's own RCCL calls
         xdev = "cpu" if args.rehearse else dev
         ex = vdist.BandStitchExchange(W, H, xdev, depth=depth) if banded else vdist.TileExchange(W, H, xdev, depth=depth)
         t.set_tile_shard(rank, world, ex.skew)
@@ -255,7 +260,9 @@ def main():
             if args.rehearse:                                        # the same steps with a hop through host memory (gloo)
                 side.synchronize()
                 ex.output(slot).copy_(out)
-            if banded:
+            if cabi_bands:                                           # vf_dist_exchange_bands: all-to-all + band stitch + in-place band gather, no torch
+                t.dist_exchange_bands(comm, 0, image.data_ptr() if rank == 0 else 0, side.cuda_stream)
+            elif banded:
                 def stitch_band(recv, band, rows):                   # [ranks][chunk] tile slots -> the rows of this rank's band (the C-ABI's kernel)
                     src, dst = (dev_gathered.copy_(recv), dev_band) if args.rehearse else (recv, band)
                     t.stitch_tiles(src.data_ptr(), dst.data_ptr(), world, 0, ex.chunk_tiles, side.cuda_stream, height=rows)
@@ -362,7 +369,7 @@ def main():
         extra = {"camera": other, "value": W * H * n2 / dt2 / 1e6, "ms_per_step": dt2 / n2 * 1e3, "tile_kernel_ms": tm2["tile_ms"]}
 
     check = None
-    if args.check and not c5:
+    if (args.check or world > 1) and not c5:                         # N > 1: always -- untimed, after the timed region
         t.set_uniforms(camera_uniforms(args.camera, W, H))
         step()
         flush()
@@ -409,7 +416,13 @@ def main():
                     frag_pm = {"stale": True}
             except Exception:  # noqa: BLE001
                 frag_pm = None
+            meas = frag_pm.get("hbm_bytes_per_launch_fetch_uncorrected") if frag_pm and not frag_pm.get("stale") else None
+            meas2 = frag_pm.get("hbm_bytes_per_launch") if frag_pm and not frag_pm.get("stale") else None
             frag[name] = {"traffic": frag_pm,
+                          # the same launch priced on the bytes the counters SAW instead of SURVEY's B_frag (which charges every height
+                          # texel once whether or not the camera shows it): uncorrected FETCH_SIZE + WRITE_SIZE, and with the guide's x2 on fetch
+                          "frac_on_measured_bytes": (meas / s / 1e9 / HBM_PEAK_GBPS) if meas else None,
+                          "frac_on_measured_bytes_fetch_x2": (meas2 / s / 1e9 / HBM_PEAK_GBPS) if meas2 else None,
                           "ms": ft["resolve_ms"], "covered_pixels": ft["covered_pixels"], "bytes": b_frag,
                           "GB/s": b_frag / s / 1e9, "frac": b_frag / s / 1e9 / HBM_PEAK_GBPS,
                           "bytes_covered_only": b_cov, "frac_covered_only": b_cov / s / 1e9 / HBM_PEAK_GBPS,
@@ -427,6 +440,31 @@ def main():
             torch.cuda.synchronize()
             cold.append((time.perf_counter() - c0) * 1e3)
         fresh.close()
+
+    # ---- the drop-in API end to end (src/terrain/mod.rs:410-491: render -> copy_texture_to_buffer -> map -> PNG): what a caller of the
+    #      reference's classes waits for, per BASELINE configuration; never part of `value` -------------------------------------------
+    api_latency = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_api_latency and not c5:
+        import tempfile
+        api_latency = {"clock": "host wall clock around the call, best of 4 after one warm-up call", "png_threads": os.environ.get("VF_PNG_THREADS", "default (up to 16)")}
+        with tempfile.TemporaryDirectory() as tmpd:
+            def best(fn, n=4):
+                fn()
+                ts = []
+                for _ in range(n):
+                    c0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - c0) * 1e3)
+                return min(ts)
+            spike = vf.TerrainSpike(800, 600, grid=128, colormap="viridis")
+            spike.set_camera_look_at((3.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0, 0.1, 100.0)
+            api_latency["C2 TerrainSpike 800x600 grid=128"] = {"render_png": best(lambda: spike.render_png(os.path.join(tmpd, "c2.png"))),
+                                                               "render_rgba": best(lambda: spike.render_rgba())}
+            del spike
+            for label, (w, h, g, seed) in (("C3 Scene 1920x1080 grid=1024", (1920, 1080, 1024, 20250815)), ("C4 Scene 4096x4096 grid=4096", (W, H, G, 20250816))):
+                sc = vf.Scene(w, h, grid=g, colormap="viridis")
+                sc.set_height_from_r32f(height_host if (g, seed) == (G, 20250816) else
+                                        np.random.default_rng(seed).random((g, g), dtype=np.float32) * np.float32(0.5) - np.float32(0.25))
+                api_latency[label] = {"render_png": best(lambda: sc.render_png(os.path.join(tmpd, "s.png"))), "render_rgba": best(lambda: sc.render_rgba())}
+                del sc
 
     # ---- roofline of the dominant kernel (k_tile: set-up + raster + fragment, fused) --------------------------------------
     # algorithmic bytes per launch (whole frame): height texture read once + RGBA8 written once + LUT
@@ -495,6 +533,20 @@ def main():
                          f"{threads} threads (every CPU this process may use), oracle/vf_oracle.c gcc -O2 OpenMP; the reference's wgpu "
                          f"software-adapter path cannot be built in this image"}
 
+    # ---- who ran: one entry per rank, so that an N > 1 line proves its own rank count and devices --------------------------------
+    ranks_info = rccl = None
+    if world > 1:
+        di = t.device_info()
+        mine = {"rank": rank, "hip_device": local_rank, "pci_bus_id": f"{di['pci_bus_id']:02x}:{di['pci_device_id']:02x}", "name": di["name"],
+                "local_tiles": t.local_tiles() if not c5 else None, "pid": os.getpid()}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        rccl = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+                "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if not args.rehearse else None,
+                "distinct_devices": len({(r["hip_device"], r["pci_bus_id"]) for r in ranks_info})}
+        if comm is not None:
+            rccl["version_c_abi"] = t.dist_version()
+
     if rank == 0:
         if c5:
             metric = f"Mpix/s terrain shade (grid={G}, {W}x{H}, 64-pose orbit batch)"
@@ -506,7 +558,8 @@ def main():
             workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
             par = ("1 GPU, whole frame" if world == 1 else
                    f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), " +
-                   ("all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
+                   ("all-to-all (RCCL through the C-ABI, vf_dist_exchange_bands) + one band stitched per rank + bands gathered in place on rank 0, " if cabi_bands else
+                    "all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
                     f"p2p gather to rank 0 ({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, ") +
                    f"{'serial' if args.serial else 'double-buffered'}")
         out = {
@@ -529,16 +582,34 @@ def main():
             out["cold_frames_ms"] = {"first (planned from the static estimate: no feedback yet)": cold[0], "second (first frame's feedback)": cold[1], "third": cold[2]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+            out["rccl"] = rccl
+        if api_latency is not None:
+            out["api_latency_ms"] = api_latency
         if args.rehearse:
             out["rehearsal"] = "gloo via host memory on one GPU; not a performance number"
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        torch.cuda.synchronize()
-        t.dist_comm_destroy(comm)
-    t.close()
+    # Teardown.  torch's current stream is the handle's own (ExternalStream above) and t.close() destroys it: give torch its default
+    # stream back and drain first, and take the process group down BEFORE the handle -- ProcessGroupNCCL records events on the
+    # current stream in barrier() / destroy_process_group().
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    failed = check is False
     if world > 1:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device="cpu" if args.rehearse else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)                  # every rank leaves with the same code
+        failed = bool(flag.item())
         dist.barrier()
+    if comm is not None:
+        t.dist_comm_destroy(comm)
+    if world > 1:
         dist.destroy_process_group()
+    t.close()
+    if failed:
+        if rank == 0:
+            print("bench.py: the gathered frame differs from the single-rank frame -- the line above is not a valid measurement", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

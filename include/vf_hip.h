@@ -252,9 +252,12 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
  *   frame:   vf_terrain_set_tile_shard(t, rank, nranks, skew); vf_terrain_set_output_device(t, slab); vf_terrain_render(t, s);
  *            vf_dist_gather_tiles(t, comm, 0, gathered, stride_tiles, s);      (all ranks; `gathered` used on the root)
  *            root: vf_stitch_tiles_device(ctx, gathered, image, W, H, nranks, skew, stride_tiles, s);
+ *   or, with column stripes (skew 0) and a tile grid that divides by nranks -- the default of bench.py:
+ *            vf_dist_exchange_bands(t, comm, 0, image, s);                     (all ranks; `image` used on the root; no root stitch)
  */
 #define VF_DIST_UNIQUE_ID_BYTES 128
 int vf_dist_available(void);                                   /* 1 when RCCL could be resolved in this process */
+int vf_dist_version(int *version);                             /* ncclGetVersion of the RCCL this process resolved (e.g. 22703) */
 int vf_dist_unique_id(uint8_t id[VF_DIST_UNIQUE_ID_BYTES]);    /* ncclGetUniqueId */
 int vf_dist_comm_init(vf_ctx *ctx, const uint8_t id[VF_DIST_UNIQUE_ID_BYTES], int rank, int nranks, void **comm);   /* ncclCommInitRank on ctx's device */
 void vf_dist_comm_destroy(void *comm);                         /* ncclCommDestroy on the communicator's own device */
@@ -273,6 +276,20 @@ int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gat
 /* Band shards (vf_terrain_set_shard) -> rank `root`: every band is a contiguous band_h * W * 4-byte slab of the final image,
  * so the root receives each remote band in place in `dev_image` ((H, W, 4), no stitch pass) and copies its own. */
 int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream);
+/* Tile shards in column stripes (vf_terrain_set_tile_shard with skew 0) -> the row-major (H, W, 4) frame in `dev_image` on rank
+ * `root`, with the stitch sharded like the rendering -- no rank copies the whole frame (round 3 measured +40..107 us on the root
+ * of eight for a whole-frame stitch, +11 us per rank this way).  One call per frame on every rank, all queued on `stream`:
+ *   1. all-to-all (one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd): the frame is cut into nranks horizontal
+ *      bands of whole tile rows; a rank's slab holds the tiles of band b contiguously and sends that chunk to rank b;
+ *   2. k_stitch_tiles on the rank's band (H / nranks rows; the root stitches straight into `dev_image`);
+ *   3. the bands are contiguous slabs of the frame: one more group moves them to the root in place.
+ * Needs W, H multiples of 64 and tile columns / tile rows that divide by nranks (C4: 2, 4, 8 ranks); every rank checks that, the
+ * communicator (rank / size == the handle's shard) and `root` before anything is posted, so all ranks fail together.  The
+ * receive chunks and (off the root) the band live in the handle and are reused by the next call: calls on one handle are
+ * ordered on one stream or by the caller's events.  `dev_image` is ignored off the root.
+ * There is no reference counterpart (single device: src/terrain/mod.rs:277-294); the module surface it extends is
+ * src/lib.rs:961-976. */
+int vf_dist_exchange_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream);
 
 /* ---- diagnostics: the fragment stage on its own (BASELINE.json north_star names it) ----------------------------
  * Renders the frame vf_terrain_render drew last (the current uniforms before the first render) once with the visibility store enabled (into scratch buffers: the handle's output, feedback

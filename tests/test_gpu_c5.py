@@ -36,6 +36,9 @@ def test_c5_orbit_poses_full_size(oracle, luts):
                 strips += int((t.item_stats()[:, 0] >> 24).astype(bool).sum())
                 ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
                 assert np.array_equal(rgba, ref_rgba), k
+                # the same pose with the default (FAST) arithmetic, directly against the oracle: within 1 LSB
+                t.set_shade_precision(1); t.render(); fast = t.read_rgba(); t.set_shade_precision(0)
+                assert int(np.abs(fast.astype(np.int16) - ref_rgba.astype(np.int16)).max()) <= 1, k
                 t.enable_timing(False)
                 assert np.array_equal(t.read_visibility(), ref_vis), k
                 t.enable_timing(True)

@@ -1,6 +1,7 @@
 """The multi-GPU exchange behind the C-ABI (include/vf_hip.h: vf_dist_*), on the real backend as far as one GPU allows: a
 one-rank RCCL communicator made with vf_dist_unique_id + vf_dist_comm_init, the tile shard of "rank 0 of 1" sent through
-ncclSend / ncclRecv to itself by vf_dist_gather_tiles, then stitched -- the result must be the unsharded frame.  Runs in a
+ncclSend / ncclRecv to itself by vf_dist_gather_tiles, then stitched -- the result must be the unsharded frame; the same through
+vf_dist_exchange_bands (column stripes -> all-to-all + band stitch + in-place band gather: bench.py's default layout).  Runs in a
 fresh interpreter without torch: the library resolves RCCL by itself (ROCm's librccl.so.1)."""
 import os
 import subprocess
@@ -63,6 +64,31 @@ assert hip.hipMemset(image, 0, W * H * 4) == 0
 t.dist_gather_bands(comm, 0, image); t.sync()
 assert hip.hipMemcpy(out.ctypes.data, image, W * H * 4, 2) == 0
 assert np.array_equal(out, whole)
+# ---- column stripes -> all-to-all + band stitch + in-place band gather (vf_dist_exchange_bands), on a frame of whole tiles ----
+t.close()
+W2, H2 = 960, 640
+u2 = np.load(os.environ["VF_UNIFORMS2"])
+t = cabi.Terrain(W2, H2, G, luts["viridis"]); t.set_height(h); t.set_uniforms(u2)
+t.render(); whole2 = t.read_rgba()
+slab2, image2 = dmalloc((W2 // 64) * (H2 // 64) * 16384), dmalloc(W2 * H2 * 4)
+t.set_tile_shard(0, 1, 0); t.set_output_device(slab2)
+out2 = np.empty((H2, W2, 4), np.uint8)
+for rep in range(3):                                        # the handle's staging buffers are reused
+    assert hip.hipMemset(image2, 0, W2 * H2 * 4) == 0
+    t.render(); t.dist_exchange_bands(comm, 0, image2); t.sync()
+    assert hip.hipMemcpy(out2.ctypes.data, image2, W2 * H2 * 4, 2) == 0
+    assert np.array_equal(out2, whole2), rep
+assert t.dist_version() > 20000
+# argument checks, made on every rank before anything is posted: wrong root, a skewed shard, a frame that cuts tiles
+try: t.dist_exchange_bands(comm, 1, image2); raise SystemExit("expected an error")
+except cabi.VfError: pass
+t.set_tile_shard(0, 1, 3); t.render()
+try: t.dist_exchange_bands(comm, 0, image2); raise SystemExit("expected an error")
+except cabi.VfError as e: assert "skew 0" in str(e)
+t.close()
+t = cabi.Terrain(W, H, G, luts["viridis"]); t.set_height(h); t.set_uniforms(u); t.set_tile_shard(0, 1, 0); t.render()
+try: t.dist_exchange_bands(comm, 0, image); raise SystemExit("expected an error")
+except cabi.VfError as e: assert "whole tiles" in str(e)
 t.dist_comm_destroy(comm)
 t.close()
 print("CABI GATHER OK")
@@ -75,6 +101,8 @@ def test_rccl_gather_through_the_c_abi(oracle, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     upath = tmp_path / "u.npy"
     np.save(upath, oracle.look_at_uniforms(1, 1000, 700, *FILL_CAMERA))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VF_ROOT=root, VF_UNIFORMS=str(upath))
+    upath2 = tmp_path / "u2.npy"
+    np.save(upath2, oracle.look_at_uniforms(1, 960, 640, *FILL_CAMERA))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VF_ROOT=root, VF_UNIFORMS=str(upath), VF_UNIFORMS2=str(upath2))
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "CABI GATHER OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -1,8 +1,9 @@
 """A bounded slice of the parity soak (tests/soak_parity.py) inside the driver-run suite: a few hundred seeded random frames,
 four frames per handle so that the compared ones are planned with scheduling feedback (strips), a quarter of them also
 rendered as 2..8 band or tile shards and stitched.  EXACT precision: visibility bit-exact, RGBA equal to the oracle; FAST
-(default) precision: within 1 LSB.  The slice moves with the day, so successive driver runs cover different seeds."""
-import time
+(default) precision: within 1 LSB.  Fixed seeds (a failure reproduces from the commit alone); VF_SOAK_FIRST_SEED moves the window,
+and tools/profile_round.sh's long soak runs on fresh seeds every time."""
+import os
 
 import pytest
 
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_soak_slice(oracle):
     import soak_parity
-    first = 200000 + (int(time.time()) // 86400 % 1000) * 1000
+    first = int(os.environ.get("VF_SOAK_FIRST_SEED", "204000"))
     res = soak_parity.run(first=first, cases=400, budget=60.0, verbose=False)
     print("\n" + res["summary"])
     assert res["cases"] >= 40, res["summary"]

@@ -7,7 +7,7 @@ mkdir -p "$out"
 n=0
 for ctr in "$@"; do
   n=$((n+1))
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/$out/pmc_${cam}_$n" -o run -- python3 "$GRAFT_REPO_ROOT/tools/exp_fragment.py" $cam > "$GRAFT_REPO_ROOT/$out/pmc_${cam}_$n.log" 2>&1) || { echo "pass $n failed"; tail -5 "$out/pmc_${cam}_$n.log"; exit 1; }
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/$out/pmc_${cam}_$n" -o run -- python3 "$GRAFT_REPO_ROOT/tools/exp_fragment.py" $cam > "$GRAFT_REPO_ROOT/$out/pmc_${cam}_$n.log" 2>&1) || { echo "pass $n failed"; tail -5 "$out/pmc_${cam}_$n.log"; exit 1; }
   f=$(find "$out/pmc_${cam}_$n" -name "*counter_collection.csv" | head -1)
   cp "$f" "$out/pmc_${cam}_$n.csv"
   python3 - "$out/pmc_${cam}_$n.csv" <<'PY'

@@ -6,7 +6,7 @@
 out=gpurun_out/$1; ctr=$2; shift; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/$out/pmc" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra "$@" > "$GRAFT_REPO_ROOT/$out/bench_pmc.json" 2> "$GRAFT_REPO_ROOT/$out/bench_pmc.err"
+timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/$out/pmc" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra "$@" > "$GRAFT_REPO_ROOT/$out/bench_pmc.json" 2> "$GRAFT_REPO_ROOT/$out/bench_pmc.err"
 cd "$GRAFT_REPO_ROOT"
 f=$(find "$out/pmc" -name "*counter_collection.csv" | head -1)
 cp "$f" "$out/counter_collection.csv"

@@ -7,7 +7,7 @@ mkdir -p "$out"
 R="$GRAFT_REPO_ROOT"
 for pass in "a:SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS" "b:GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA"; do
   name=${pass%%:*}; ctr=${pass#*:}
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --output-format csv -d "$R/$out/pmc_$name" -o run -- python3 "$R/tools/exp_rank_trace.py" "$@" > "$R/$out/pmc_$name.log" 2> "$R/$out/pmc_$name.err") || exit 1
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d "$R/$out/pmc_$name" -o run -- python3 "$R/tools/exp_rank_trace.py" "$@" > "$R/$out/pmc_$name.log" 2> "$R/$out/pmc_$name.err") || exit 1
   cp "$(find $out/pmc_$name -name '*counter_collection.csv' | head -1)" "$out/pmc_$name.csv"
   python3 tools/pmc_sq_summary.py "$out/pmc_$name.csv"
 done

@@ -5,7 +5,7 @@
 out=gpurun_out/$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/prof" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra "$@" > "$GRAFT_REPO_ROOT/$out/bench_prof.json" 2> "$GRAFT_REPO_ROOT/$out/bench_prof.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/prof" -o run -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra "$@" > "$GRAFT_REPO_ROOT/$out/bench_prof.json" 2> "$GRAFT_REPO_ROOT/$out/bench_prof.err"
 cd "$GRAFT_REPO_ROOT"
 f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
 cp "$f" "$out/kernel_stats.csv"

@@ -23,7 +23,7 @@ SYMBOLS = [
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_frame_times", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
-    "vf_dist_available", "vf_dist_unique_id", "vf_dist_comm_init", "vf_dist_comm_destroy", "vf_dist_gather_tiles", "vf_dist_gather_bands",
+    "vf_dist_available", "vf_dist_version", "vf_dist_unique_id", "vf_dist_comm_init", "vf_dist_comm_destroy", "vf_dist_gather_tiles", "vf_dist_gather_bands", "vf_dist_exchange_bands",
     "vf_terrain_debug_fragment_stage",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
     "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
@@ -86,11 +86,13 @@ _PROTOS = {
     "vf_stitch_bands_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     "vf_stitch_tiles_device": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp]),
     "vf_dist_available": (_i, []),
+    "vf_dist_version": (_i, [C.POINTER(_i)]),
     "vf_dist_unique_id": (_i, [_vp]),
     "vf_dist_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "vf_dist_comm_destroy": (None, [_vp]),
     "vf_dist_gather_tiles": (_i, [_vp, _vp, _i, _vp, _u32, _vp]),
     "vf_dist_gather_bands": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "vf_dist_exchange_bands": (_i, [_vp, _vp, _i, _vp, _vp]),
     "vf_terrain_debug_fragment_stage": (_i, [_vp, _u32, C.POINTER(FragmentTiming)]),
     "vf_dem_create": (_i, [_vp, C.POINTER(_vp)]),
     "vf_dem_destroy": (None, [_vp]),
@@ -161,6 +163,12 @@ class Terrain:
             self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+    def device_info(self):
+        """dict of the vf_device_info of this handle's device (name, arch, ordinal, PCI bus / device id, ...)."""
+        di = DeviceInfo()
+        self._check(self.lib.vf_ctx_device_info(self.ctx, C.byref(di)))
+        return {k: (getattr(di, k).decode() if isinstance(getattr(di, k), bytes) else getattr(di, k)) for k, _ in DeviceInfo._fields_}
 
     def stream_handle(self):
         """hipStream_t of the context's own stream (what stream=None means), e.g. for torch.cuda.ExternalStream."""
@@ -234,6 +242,15 @@ class Terrain:
 
     def dist_gather_bands(self, comm, root, image_dptr, stream=None):
         self._check(self.lib.vf_dist_gather_bands(self.t, _vp(comm), int(root), _vp(image_dptr or 0), _vp(stream or 0)))
+
+    def dist_exchange_bands(self, comm, root, image_dptr, stream=None):
+        """Column-stripe tile shards -> the frame on `root`: all-to-all + one band stitched per rank + bands gathered in place."""
+        self._check(self.lib.vf_dist_exchange_bands(self.t, _vp(comm), int(root), _vp(image_dptr or 0), _vp(stream or 0)))
+
+    def dist_version(self):
+        v = _i()
+        self._check(self.lib.vf_dist_version(C.byref(v)))
+        return v.value
 
     def fragment_stage(self, repeats=10):
         """The fragment stage as a launch of its own (diagnostics): dict(resolve_ms, covered_pixels, repeats, equal_to_frame)."""

@@ -151,6 +151,9 @@ struct vf_terrain {
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
     bool rendered = false;
+    // vf_dist_exchange_bands: the chunks this rank receives in the all-to-all ([nranks][chunk_tiles] tile slots) and the band it stitches from them
+    uint8_t *d_xrecv = nullptr, *d_xband = nullptr;
+    size_t xrecv_bytes = 0, xband_bytes = 0;
 };
 
 extern "C" {
@@ -370,7 +373,7 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_merge, t->d_rgba_scratch, t->d_diag };
+    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_merge, t->d_rgba_scratch, t->d_diag, t->d_xrecv, t->d_xband };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &S : t->ps) {
         void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.flags_new, S.feedback };
@@ -430,7 +433,9 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
         // the per-block height cache and bounds depend on the texture alone: built here, behind the upload, not by the first frame
         // (a texture handed over in device memory may still be written by the caller's stream: that one is cached by the next frame)
         hipLaunchKernelGGL(k_height_blocks, dim3(t->nblocks), dim3(64), 0, t->ctx->stream, t->n, t->nb, t->tw, axis(t), t->d_height, t->d_hblk, t->d_bounds);
-        if (hipGetLastError() == hipSuccess) t->bounds_dirty = false;
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = fail(VF_ERR_HIP, std::string("k_height_blocks: ") + hipGetErrorString(le));   // (bounds stay dirty)
+        else t->bounds_dirty = false;
     }
     VF_HIP_TRY(hipStreamSynchronize(t->ctx->stream));   // host buffer is only borrowed for this call
     return rc;
@@ -1414,6 +1419,7 @@ struct Rccl {
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;   // (optional)
+    ncclResult_t (*GetVersion)(int *) = nullptr;                       // (optional)
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1438,6 +1444,7 @@ const Rccl &resolve_rccl()
         x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
         x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(sym("ncclCommUserRank"));
         x.CommCuDevice = reinterpret_cast<decltype(x.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
+        x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(dlsym(h, "ncclGetVersion"));
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
         x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
         x.Send = reinterpret_cast<decltype(x.Send)>(sym("ncclSend"));
@@ -1472,6 +1479,17 @@ extern "C" {
 
 int vf_dist_available(void) { return resolve_rccl().ok ? 1 : 0; }
 
+int vf_dist_version(int *version)
+{
+    if (!version) return fail(VF_ERR_INVALID, "NULL argument");
+    *version = 0;
+    const Rccl &R = resolve_rccl();
+    if (!R.ok) return fail(VF_ERR_HIP, R.why);
+    if (!R.GetVersion) return fail(VF_ERR_HIP, "RCCL lacks ncclGetVersion");
+    VF_RCCL_TRY(R, R.GetVersion(version));
+    return VF_OK;
+}
+
 int vf_dist_unique_id(uint8_t id[VF_DIST_UNIQUE_ID_BYTES])
 {
     if (!id) return fail(VF_ERR_INVALID, "NULL argument");
@@ -1504,9 +1522,11 @@ void vf_dist_comm_destroy(void *comm)
 {
     const Rccl &R = resolve_rccl();
     if (!R.ok || !comm) return;
-    int dev = -1;                                           // the communicator's own device, whatever the calling thread has current
+    int dev = -1, was = -1;                                 // the communicator's own device, whatever the calling thread has current ...
+    const bool have_was = hipGetDevice(&was) == hipSuccess;
     if (R.CommCuDevice && R.CommCuDevice((ncclComm_t)comm, &dev) == ncclSuccess && dev >= 0) (void)hipSetDevice(dev);
     (void)R.CommDestroy((ncclComm_t)comm);
+    if (have_was && was >= 0) (void)hipSetDevice(was);     // ... which is the caller's again afterwards
 }
 
 int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gathered, uint32_t stride_tiles, void *stream)
@@ -1598,6 +1618,83 @@ int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_ima
     const ncclResult_t end = R.GroupEnd();
     if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
     if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
+    return VF_OK;
+}
+
+// Tile shards (column stripes: skew 0) -> the row-major frame on rank `root` without any rank copying the whole frame: the stitch is
+// sharded like the rendering.  (The steps are those of vulkan_forge_amd/dist.py::BandStitchExchange, here on RCCL directly.)
+int vf_dist_exchange_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->shard_tiles) return fail(VF_ERR_INVALID, "handle is not tile-sharded");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    const Rccl &R = resolve_rccl();
+    int rc = check_comm(R, t, rccl_comm, root);
+    if (rc != VF_OK) return rc;
+    const uint32_t N = t->nranks;
+    // every rank can check the layout for itself, before anything is posted: all ranks fail together
+    if (t->skew != 0u) return fail(VF_ERR_INVALID, "the band exchange needs column stripes (tile shard with skew 0)");
+    if (t->W % (uint32_t)kTileW || t->H % (uint32_t)kTileH || t->ntx % N || t->nty % N)
+        return fail(VF_ERR_INVALID, "the band exchange needs whole tiles and tile columns / tile rows that divide by the number of ranks");
+    const bool is_root = (uint32_t)root == t->rank;
+    if (is_root && !dev_image) return fail(VF_ERR_INVALID, "the root needs the image buffer");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    ncclComm_t comm = (ncclComm_t)rccl_comm;
+    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
+    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+    const size_t tile_bytes = (size_t)kTileW * kTileH * 4;
+    const uint32_t band_tile_rows = t->nty / N, chunk_tiles = band_tile_rows * (t->ntx / N);   // tiles one rank holds of one band
+    const size_t chunk_bytes = (size_t)chunk_tiles * tile_bytes;
+    const uint32_t band_rows = t->H / N;
+    const size_t band_bytes = (size_t)band_rows * t->W * 4;
+    // the handle's own staging: what this rank receives ([N][chunk_tiles] tile slots) and, off the root, the band it stitches.
+    // Reused by every call: calls on one handle are ordered on one stream (or by the caller's events).
+    if (t->xrecv_bytes < chunk_bytes * N) {
+        if (t->d_xrecv) { VF_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(t->d_xrecv); t->d_xrecv = nullptr; t->xrecv_bytes = 0; }
+        hipError_t e = hipMalloc(&t->d_xrecv, chunk_bytes * N);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e));
+        t->xrecv_bytes = chunk_bytes * N;
+    }
+    if (!is_root && t->xband_bytes < band_bytes) {
+        if (t->d_xband) { VF_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(t->d_xband); t->d_xband = nullptr; t->xband_bytes = 0; }
+        hipError_t e = hipMalloc(&t->d_xband, band_bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("exchange buffer: ") + hipGetErrorString(e));
+        t->xband_bytes = band_bytes;
+    }
+    // 1. all-to-all: a rank's slab lists its tiles row-major by (ty, tx), so the tiles of band b are the contiguous chunk b; it goes
+    //    to rank b -- 1 / N of a slab per peer, every xGMI link busy in both directions, none a hot spot.  (Own chunk: a device copy.)
+    const uint8_t *slab = (const uint8_t *)t->d_rgba;
+    // (a one-rank communicator sends its only chunk through RCCL to itself: the loop-back test then exercises the very calls N ranks make)
+    if (N > 1u) VF_HIP_TRY(hipMemcpyAsync(t->d_xrecv + (size_t)t->rank * chunk_bytes, slab + (size_t)t->rank * chunk_bytes, chunk_bytes, hipMemcpyDeviceToDevice, s));
+    {
+        VF_RCCL_TRY(R, R.GroupStart());
+        ncclResult_t res = ncclSuccess;
+        for (uint32_t r = 0; r < N && res == ncclSuccess; ++r) {
+            if (r == t->rank && N > 1u) continue;
+            res = R.Send(slab + (size_t)r * chunk_bytes, chunk_bytes, ncclUint8, (int)r, comm, s);
+            if (res == ncclSuccess) res = R.Recv(t->d_xrecv + (size_t)r * chunk_bytes, chunk_bytes, ncclUint8, (int)r, comm, s);
+        }
+        const ncclResult_t end = R.GroupEnd();
+        if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
+        if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
+    }
+    // 2. every rank stitches ITS band (a frame of H / N rows whose tile (tx, ty) sits in slot [tx % N][ty * (ntx / N) + tx / N]):
+    //    1 / N of the copy each; the root writes its band straight into the image
+    uint8_t *const band = is_root ? (uint8_t *)dev_image + (size_t)t->rank * band_bytes : t->d_xband;
+    rc = vf_stitch_tiles_device(t->ctx, t->d_xrecv, band, t->W, band_rows, N, 0u, chunk_tiles, s);
+    if (rc != VF_OK) return rc;
+    // 3. the bands are contiguous slabs of the final image: the root receives them in place
+    if (N > 1u) {
+        VF_RCCL_TRY(R, R.GroupStart());
+        ncclResult_t res = ncclSuccess;
+        if (is_root) {
+            for (uint32_t r = 0; r < N && res == ncclSuccess; ++r)
+                if (r != t->rank) res = R.Recv((uint8_t *)dev_image + (size_t)r * band_bytes, band_bytes, ncclUint8, (int)r, comm, s);
+        } else res = R.Send(band, band_bytes, ncclUint8, root, comm, s);
+        const ncclResult_t end = R.GroupEnd();
+        if (res != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(res));
+        if (end != ncclSuccess) return fail(VF_ERR_HIP, std::string("ncclGroupEnd: ") + R.GetErrorString(end));
+    }
     return VF_OK;
 }
 

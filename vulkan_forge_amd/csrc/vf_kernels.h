@@ -1302,7 +1302,9 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // in `redo`.  COMPLETE = true is a small persistent launch that renders the filed items again, this time with the generic
 // path (Sutherland-Hodgman clipping, per-pixel int64 coverage).  Keeping that path -- non-inlined calls, stack arrays -- out
 // of the main kernel is what lets it live in 96 vector registers (VF_TILE_MIN_WAVES, vf_device.h: the next frame's set-up kernel
-// shares the CUs with it); the 28 registers it spills at that cap are spilled outside the block loop.
+// shares the CUs with it).  At that cap it spills 64 bytes per lane (profiles/r03_isa_stats.txt, tools/isa_stats.py): the stores at
+// kernel entry and in the item loop, the reloads in the item and chunk loops -- and ONE reload per pulled block (loop depth 3, the
+// block pull loop); none in pass A, pass B, the line loop or the paint loop.
 template <bool WRITE_VIS, bool COMPLETE, bool FAST>
 __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameParams P, SetupView V, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
@@ -1596,6 +1598,14 @@ next_item:
             const uint32_t bidx = by * P.nb + bx;
             // (wave-uniform address, data the set-up pass wrote before this launch: read through the scalar cache into scalar registers --
             //  the box arithmetic of the late cull below then runs on the scalar unit)
+            // SCALAR-CACHE COHERENCE, the assumption this rests on: k_block_setup wrote the record with VECTOR stores, on another
+            // stream, into a buffer the tile kernel of two frames ago read through the scalar cache at the same address.  The scalar
+            // cache is not coherent with vector stores; what makes the read safe is the kernel boundary: every dispatch begins with an
+            // acquire that invalidates the scalar (and vector L1) caches of the CUs it lands on, and the producer's release at its end
+            // writes the record back to L2 before the event this launch waits on signals.  A record can therefore only be stale if it
+            // were rewritten WHILE this launch runs -- and the plan state this launch reads is not written again before its `drawn`
+            // event (render_impl: the next user of the set waits for it).  tests/test_gpu_parity.py::
+            // test_records_rewritten_every_frame_are_never_read_stale rewrites both sets with different records 20 frames in a row.
             typedef uint32_t __attribute__((ext_vector_type(8))) rec_words;
             const rec_words rw = *(const __attribute__((address_space(4))) rec_words *)(uintptr_t)(V.recs + bidx);
             const uint4 r_lo = make_uint4(rw[0], rw[1], rw[2], rw[3]), r_hi = make_uint4(rw[4], rw[5], rw[6], rw[7]);   // box (2 words), flags, count | alive_even, alive_odd
