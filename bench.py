@@ -337,6 +337,7 @@ def main():
         dt = time.perf_counter() - t0
         tm = t.timings()
         tm["frame_tile_ms"], tm["frame_period_ms"] = t.frame_times()
+        tm["raster_groups"] = t.raster_groups()
         t.enable_timing(False)
         if world > 1:
             x = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -570,6 +571,9 @@ def main():
             "settle_frames": SETTLE,
             "frame_ms": frame_ms,
             "shade_precision": "fast (hardware rcp/rsq/sin/cos/log/exp, within 1 LSB of the exact path; visibility identical)",
+            # which of the raster stage's two line loops drew the timed frames (the handle times both on the settle frames and keeps the
+            # faster per view: vf_terrain_set_raster_groups) and what its probes measured for the main tile kernel alone
+            "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "tile_kernel_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
             "roofline": roofline,
             "roofline_fragment": frag,
             "cpu_baseline": cpu,

@@ -126,6 +126,14 @@ int vf_terrain_set_shade_mode(vf_terrain *t, int mode);
 #define VF_PRECISION_EXACT 0
 #define VF_PRECISION_FAST 1
 int vf_terrain_set_shade_precision(vf_terrain *t, int precision);
+/* The raster stage's line loop exists twice (round 4): with and without a first pass that tests a triangle's lines in groups of four
+ * against the final-pixel masks.  Which one is faster depends on the view and on how the frame is cut (wide items with many-line
+ * triangles gain, a multi-GPU rank's narrow strips lose); the picture never differs.  mode -1 (default): the handle times both on
+ * its own frames (HIP events around the tile kernel, read back frames later, never a wait) and keeps the faster one per view;
+ * 0 / 1: fixed.  No reference counterpart: the fixed-function raster behind draw_indexed, src/terrain/mod.rs:435. */
+int vf_terrain_set_raster_groups(vf_terrain *t, int mode);
+/* which variant drew the last frame (0 / 1) and, when measured, the tile-kernel time of each in this view (ms; 0 = not measured) */
+int vf_terrain_raster_groups(const vf_terrain *t, int *in_use, float ms[2]);
 
 /* Multi-GPU screen split (new; the reference is single-device).  Pixel row y belongs to this
  * object iff ((y / band_h) % nranks) == rank; owned rows are stored densely ("local rows") in

@@ -5,7 +5,8 @@
 // For every random triangle x tile window x line it requires
 //   - stage 1 (span_line) to contain the true span,
 //   - stage 2 (span_confirm), when it accepts, to make the stage-1 span equal to the true span,
-//   - span_exact to equal the true span always.
+//   - span_exact to equal the true span always,
+//   - the group bound (span_group) of every run of up to four adjacent lines to contain the stage-1 span of each of its lines.
 // It also reports how often stage 2 falls back (the FP32 path must decide nearly every line by itself).
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ int main(int argc, char **argv)
     auto uni = [&](int64_t lo, int64_t hi) { return (int64_t)(lo + (int64_t)(rng() % (uint64_t)(hi - lo + 1))); };
     long lines = 0, nonempty = 0, fallback = 0, irregular_tris = 0, tris = 0, bad = 0;
     long k_tris[10] = {0}, k_irr[10] = {0}, k_lines[10] = {0}, k_fb[10] = {0};
+    long group_lines = 0, group_slack = 0;
     for (long c = 0; c < cases && bad < 10; ++c) {
         int32_t X[3], Y[3];
         const int kind = (int)uni(0, 9);
@@ -80,6 +82,19 @@ int main(int argc, char **argv)
         span_setup(U, V, !cols, u0c, v0c, n_outer, S);
         irregular_tris += S.regular ? 0 : 1;
         k_tris[kind]++; k_irr[kind] += S.regular ? 0 : 1;
+        if (S.regular)                                     // stage 0: the bound of lines oa .. oa + 3 holds every one of their stage-1 spans
+            for (int32_t oa = 0; oa <= n_outer && bad < 10; oa += 4) {
+                const int32_t ob = std::min(oa + 3, n_outer);
+                int32_t glo, ghi;
+                span_group(S, oa, ob, n_inner, glo, ghi);
+                for (int32_t o = oa; o <= ob; ++o) {
+                    int32_t F[3], lo, hi;
+                    span_line(S, o, n_inner, F, lo, hi);
+                    ++group_lines;
+                    if (lo <= hi && (glo > lo || ghi < hi)) { printf("group bound cuts a line: case %ld lines %d..%d line %d: [%d,%d] vs group [%d,%d]\n", c, oa, ob, o, lo, hi, glo, ghi); ++bad; break; }
+                    group_slack += (lo <= hi) ? (lo - glo) + (ghi - hi) : 0;
+                }
+            }
         for (int32_t o = 0; o <= n_outer; ++o) {
             ++lines; k_lines[kind]++;
             int32_t tlo = n_inner + 1, thi = -1;           // brute force: first / last covered offset (coverage along a line is an interval)
@@ -112,6 +127,7 @@ int main(int argc, char **argv)
     }
     printf("triangles %ld (irregular %ld = %.3f %%)  lines %ld  non-empty %ld  stage-2 fallbacks %ld (%.4f %% of lines)  failures %ld\n",
            tris, irregular_tris, 100.0 * irregular_tris / (tris ? tris : 1), lines, nonempty, fallback, 100.0 * fallback / (lines ? lines : 1), bad);
+    printf("group bounds: %ld lines checked, mean slack %.2f pixels per non-empty line\n", group_lines, (double)group_slack / (group_lines ? group_lines : 1));
     for (int k = 0; k < 10; ++k) printf("  kind %d: triangles %ld irregular %.3f %%  lines %ld fallback %.4f %%\n", k, k_tris[k], 100.0 * k_irr[k] / (k_tris[k] ? k_tris[k] : 1), k_lines[k], 100.0 * k_fb[k] / (k_lines[k] ? k_lines[k] : 1));
     return bad ? 1 : 0;
 }

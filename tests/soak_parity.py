@@ -51,6 +51,7 @@ def run(first=5000, cases=200, budget=400.0, huge=False, verbose=True):
         t = cabi.Terrain(W, H, G, luts[cmap])
         try:
             t.set_uniforms(u); t.set_shade_mode(mode); t.set_height(h)
+            t.set_raster_groups(int(rng.integers(-1, 2)))  # either line loop of the raster stage, or the handle's own choice
             for _ in range(8 if huge else 4): t.render()       # default precision (FAST)
             fast = t.read_rgba()
             t.set_shade_precision(0)                           # EXACT

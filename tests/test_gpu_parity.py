@@ -514,6 +514,45 @@ def test_height_reupload_and_resize(cabi, oracle, luts):
         t.close()
 
 
+@pytest.mark.parametrize("case", ["noise_640x360_g256", "fill_900x700_g384", "c3_1080p_g1024", "strips_rank_of_8"])
+def test_both_line_loops_of_the_raster_draw_the_same_frame(cabi, oracle, luts, case):
+    """The raster stage's line loop exists with and without the group pass (vf_terrain_set_raster_groups; left alone, a handle times both
+    and keeps the faster per view).  Forced either way, and left to choose over enough frames to have probed both, a handle must
+    give the same bytes -- FAST and EXACT, visibility included -- and the EXACT ones are the oracle's."""
+    W, H, G, cam, shard = {"noise_640x360_g256": (640, 360, 256, DEFAULT_CAMERA, None), "fill_900x700_g384": (900, 700, 384, FILL_CAMERA, None),
+                           "c3_1080p_g1024": (1920, 1080, 1024, DEFAULT_CAMERA, None), "strips_rank_of_8": (2048, 2048, 2048, DEFAULT_CAMERA, (3, 8))}[case]
+    h = heightmap(len(case), G)
+    u = oracle.look_at_uniforms(1, W, H, *cam)
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_height(h); t.set_uniforms(u)
+        frames = {}
+        for mode in (0, 1, -1):
+            t.set_raster_groups(mode)
+            if shard: t.set_tile_shard(shard[0], shard[1], 0)
+            else: t.set_shard(0, 1, 64)
+            for _ in range(18 if mode < 0 else 4):                  # (-1: past both probe windows)
+                t.render()
+            fast = t.read_tiles() if shard else t.read_rgba()
+            if mode >= 0:
+                assert t.raster_groups()[0] == mode
+            t.set_shade_precision(EXACT); t.render()
+            exact = t.read_tiles() if shard else t.read_rgba()
+            t.set_shade_precision(FAST)
+            frames[mode] = (fast, exact)
+        assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
+        assert np.array_equal(frames[-1][0], frames[0][0]) and np.array_equal(frames[-1][1], frames[0][1])
+        if not shard:
+            ref_rgba, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=min(16, oracle.max_threads()))
+            assert np.array_equal(frames[0][1], ref_rgba)
+            note_fast(frames[0][0], ref_rgba)
+            for mode in (0, 1):
+                t.set_raster_groups(mode)
+                assert np.array_equal(t.read_visibility(), ref_vis), mode
+    finally:
+        t.close()
+
+
 def test_records_rewritten_every_frame_are_never_read_stale(cabi, oracle, luts):
     """k_tile reads a block's record through the SCALAR cache (constant-address-space load, vf_kernels.h "scalar-cache coherence")
     although k_block_setup wrote it with vector stores, on another stream, a frame earlier in the same buffer: that relies on the

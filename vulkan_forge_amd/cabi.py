@@ -18,7 +18,7 @@ VF_OK, VF_ERR_NO_DEVICE, VF_ERR_HIP, VF_ERR_INVALID, VF_ERR_NOMEM = 0, -1, -2, -
 SYMBOLS = [
     "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info", "vf_ctx_stream",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
-    "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
+    "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_raster_groups", "vf_terrain_raster_groups", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_frame_times", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
@@ -62,6 +62,8 @@ _PROTOS = {
     "vf_terrain_set_height_device": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_set_shade_mode": (_i, [_vp, _i]),
     "vf_terrain_set_shade_precision": (_i, [_vp, _i]),
+    "vf_terrain_set_raster_groups": (_i, [_vp, _i]),
+    "vf_terrain_raster_groups": (_i, [_vp, C.POINTER(_i), _vp]),
     "vf_terrain_set_shard": (_i, [_vp, _u32, _u32, _u32]),
     "vf_terrain_local_rows": (_i, [_vp, C.POINTER(_u32)]),
     "vf_terrain_set_tile_shard": (_i, [_vp, _u32, _u32, _u32]),
@@ -195,6 +197,16 @@ class Terrain:
         """0 = EXACT (IEEE binary32 in a fixed order: the oracle bit for bit), 1 = FAST (default; hardware rcp / rsq / sin / cos /
         log / exp, within 1 LSB of EXACT, visibility identical)."""
         self._check(self.lib.vf_terrain_set_shade_precision(self.t, int(precision)))
+
+    def set_raster_groups(self, mode):
+        """-1: the handle measures both line loops of the raster stage on its own frames and keeps the faster (default); 0 / 1: fixed."""
+        self._check(self.lib.vf_terrain_set_raster_groups(self.t, int(mode)))
+
+    def raster_groups(self):
+        """(variant that drew the last frame, [tile-kernel ms without groups, with groups]; 0 = not measured in this view)"""
+        use, ms = _i(), (C.c_float * 2)()
+        self._check(self.lib.vf_terrain_raster_groups(self.t, C.byref(use), C.cast(ms, _vp)))
+        return use.value, [float(ms[0]), float(ms[1])]
 
     def set_shard(self, rank, nranks, band_h=64):
         self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))

@@ -61,6 +61,21 @@ const SrgbTables &tables()
 }
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+// (experiments only: VF_STRIPE_LOG2 = log2 of the width, in tiles, of the column stripes a tile shard deals to the ranks; the stitch
+//  kernels and the exchange know single-tile stripes only -- tools/exp_ranks.py measures the rendering side)
+uint32_t stripe_rot() { static const uint32_t v = std::getenv("VF_STRIPE_ROT") ? (uint32_t)std::atoi(std::getenv("VF_STRIPE_ROT")) : 0u; return v; }
+uint32_t stripe_owner(uint32_t g, uint32_t ty, uint32_t skew, uint32_t nranks)
+{
+    const uint32_t rot = stripe_rot();
+    if (rot == 1u) return (g + g / nranks + skew * ty) % nranks;                       // every period of stripes shifted by one rank
+    if (rot == 2u) return (((g / nranks) & 1u) ? nranks - 1u - g % nranks : g % nranks);   // every other period reversed
+    return (g + skew * ty) % nranks;
+}
+uint32_t stripe_shift()
+{
+    static const uint32_t v = [] { const char *e = std::getenv("VF_STRIPE_LOG2"); return e ? (uint32_t)std::min(std::max(std::atoi(e), 0), 4) : 0u; }();
+    return v;
+}
 uint32_t ilog2(uint32_t v)
 {
     uint32_t s = 0;
@@ -104,8 +119,15 @@ struct vf_terrain {
     bool bounds_dirty = true;
     float2 *d_bounds = nullptr;          // per block: min/max displaced height
     float *d_hblk = nullptr;             // displaced-height cache: 81 floats per block
-    // Per-frame plan state, twice: frame f uses set f & 1.  The plan kernels of a frame run on `side` and touch nothing else,
-    // so they overlap the previous frame's tile kernel (which still reads the other set) instead of waiting for it.
+    // Per-frame plan state, kPlanStates times: frame f uses set f % kPlanStates.  The plan kernels of a frame run on `side` and touch
+    // nothing else, so they overlap the previous frames' tile kernels (which still read the other sets) instead of waiting for them.
+    // (VF_PLAN_STATES 3 and VF_OVERLAP_FRAMES=1 are round 4's experiment with consecutive frames on alternating streams and output
+    //  buffers, whose tile kernels then overlap -- frame f + 1's persistent workgroups take the CUs frame f's tail leaves idle:
+    //  measured +8 % on one GPU and +6 % on a rank of eight with two streams, -1 % on the rank with three; tools/exp_overlap.py.)
+#ifndef VF_PLAN_STATES
+#define VF_PLAN_STATES 2
+#endif
+    static constexpr uint32_t kPlanStates = VF_PLAN_STATES;
     struct PlanState {
         PixelBox *ranges = nullptr;      // per block: conservative pixel rectangle (from the block's height bounds)
         VertexRec *vtx = nullptr;        // per block 81 x {X, Y, 1/w, h} (k_block_setup)
@@ -124,7 +146,9 @@ struct vf_terrain {
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
                                          // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
-    } ps[2];
+    } ps[kPlanStates];
+    uint32_t cur_set = 0, last_set = 0;  // the set the next frame takes; the set of the frame rendered last
+    const uint32_t *last_out = nullptr;  // output buffer of the frame rendered last
     hipStream_t side = nullptr;          // k_block_boxes -> k_plan -> k_plan_sort
     hipStream_t side2 = nullptr;         // k_block_setup (needs the block boxes only): beside the plan chain, both under the previous frame
     uint32_t frame_no = 0;
@@ -151,6 +175,17 @@ struct vf_terrain {
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
     bool rendered = false;
+    // Which instantiation of the tile kernel draws the frames -- with or without line groups in the raster's line loop (vf_kernels.h,
+    // raster_fast) -- is measured, like the frame plan: which one is faster depends on what the camera shows and on how the frame is
+    // cut (C4: groups -7 % on the top-down camera at any rank count, -1.5 % on one GPU at the default camera, +5 % on a rank of eight,
+    // whose items are narrow strips).  Never a difference in the picture.  groups_mode: -1 measure and choose, 0 / 1 fixed.
+    int groups_mode = -1;
+    struct GroupProbe { hipEvent_t a = nullptr, b = nullptr; int variant = 0; bool pending = false; } gprobe[8];
+    uint32_t gprobe_head = 0;
+    float g_ms[2] = { 0.0f, 0.0f };      // tile-kernel time of each variant in this epoch (mean of the probes taken)
+    uint32_t g_n[2] = { 0u, 0u };
+    uint32_t g_epoch_frames = 0;         // frames since the epoch began (shard change, height upload, camera jump)
+    int groups_now = 1;                  // the variant of the frame rendered last
     // vf_dist_exchange_bands: the chunks this rank receives in the all-to-all ([nranks][chunk_tiles] tile slots) and the band it stitches from them
     uint8_t *d_xrecv = nullptr, *d_xband = nullptr;
     size_t xrecv_bytes = 0, xband_bytes = 0;
@@ -354,6 +389,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
         for (int k = 0; k < 5 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
+    for (auto &g : t->gprobe) { if (err == hipSuccess) err = hipEventCreate(&g.a); if (err == hipSuccess) err = hipEventCreate(&g.b); }
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -391,6 +427,7 @@ void vf_terrain_destroy(vf_terrain *t)
     if (t->h_png) (void)hipHostFree(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
+    for (auto &g : t->gprobe) { if (g.a) (void)hipEventDestroy(g.a); if (g.b) (void)hipEventDestroy(g.b); }
     delete t;
 }
 
@@ -404,6 +441,7 @@ int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44])
 
 static int set_height_common(vf_terrain *t, uint32_t tw, uint32_t th)
 {
+    t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0;     // other heights: which line loop is faster is measured again
     bool resized = tw != t->tw || th != t->th;
     t->tw = tw; t->th = th;
     if (resized) return refresh_tables(t, t->ctx->stream);
@@ -473,6 +511,23 @@ int vf_terrain_set_shade_precision(vf_terrain *t, int precision)
     return VF_OK;
 }
 
+int vf_terrain_set_raster_groups(vf_terrain *t, int mode)
+{
+    if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (mode < -1 || mode > 1) return fail(VF_ERR_INVALID, "mode must be -1 (measure and choose), 0 or 1");
+    t->groups_mode = mode;
+    t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f;
+    return VF_OK;
+}
+
+int vf_terrain_raster_groups(const vf_terrain *t, int *in_use, float ms[2])
+{
+    if (!t || !in_use) return fail(VF_ERR_INVALID, "NULL argument");
+    *in_use = t->groups_now;
+    if (ms) { ms[0] = t->g_n[0] ? t->g_ms[0] : 0.0f; ms[1] = t->g_n[1] ? t->g_ms[1] : 0.0f; }
+    return VF_OK;
+}
+
 int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t band_h)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
@@ -505,7 +560,7 @@ int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nran
     uint32_t n = 0;
     for (uint32_t ty = 0; ty < nty; ++ty)
         for (uint32_t tx = 0; tx < ntx; ++tx)
-            if ((tx + skew * ty) % nranks == rank) {
+            if (stripe_owner(tx >> stripe_shift(), ty, skew, nranks) == rank) {
                 if (tiles && n < capacity) tiles[n] = tx | (ty << 16);
                 ++n;
             }
@@ -598,7 +653,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
-    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = t->skew;
+    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = t->skew; P.stripe_shift = stripe_shift(); P.stripe_rot = stripe_rot();
     P.shade_mode = t->shade_mode; P.tex = t->d_height;
     P.inv2hr = 1.0f / (2.0f * P.h_range);
     {   // cell / nm1 as mulhi(cell, m) >> s, exact for cell < 2^26 (nm1 < 2^13): s = 31 + ceil(log2 nm1) - 32, m = ceil(2^(s + 32) / nm1)
@@ -638,6 +693,9 @@ static float camera_shift_px(const vf_terrain *t, const float *a, const float *b
 }
 constexpr float kFreshFeedbackPx = 24.0f;   // from here on (3/8 of a tile per frame) the plan waits for the previous frame's feedback
 
+#ifndef VF_GROUPS_MAX_RANKS
+#define VF_GROUPS_MAX_RANKS 8    // handles sharded over this many ranks or more take the tile kernel without line groups
+#endif
 // the fast fragment path exists for fs_main as coded; the documented-only SPEC_T32 stage always takes the exact arithmetic
 static bool fast_shading(const vf_terrain *t) { return t->precision == VF_PRECISION_FAST && t->shade_mode == VF_SHADE_REFERENCE; }
 
@@ -647,8 +705,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     build_params(t, P);
     AxisTables A = axis(t);
     const uint32_t ntiles = t->local_tiles;
-    const uint32_t set = t->frame_no++ & 1u;
-    vf_terrain::PlanState &S = t->ps[set], &O = t->ps[set ^ 1u];       // this frame's plan state, the previous frame's
+    const uint32_t set = t->cur_set;
+    t->cur_set = (set + 1u) % vf_terrain::kPlanStates;
+    t->frame_no++;
+    vf_terrain::PlanState &S = t->ps[set], &O = t->ps[t->last_set];       // this frame's plan state, the previous frame's
     // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
     // a camera that moves the picture by a good part of a tile per frame waits for the previous frame instead and uses ITS feedback:
     // the plan then costs its own time (k_plan + k_plan_sort after the tile kernel), stale feedback costs more (64-pose orbit
@@ -661,7 +721,8 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     }
     // (one more frame after the motion stops: the frame before last still shows the old view, the last one the new)
     // ... and the second frame of a handle: its own plan state has no times yet, the first frame's has
-    const bool fresh = t->camera_moving || t->was_moving || t->frames_since_reset == 1;
+    // ... and the frames of a handle whose own plan state has no times yet (the sets take turns): the previous frame's has
+    const bool fresh = t->camera_moving || t->was_moving || (t->frames_since_reset >= 1 && t->frames_since_reset < vf_terrain::kPlanStates);
     const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");   // no tile times at all yet: a static estimate stands in (k_plan_estimate)
     t->frames_since_reset++;
     t->was_moving = t->camera_moving;
@@ -696,6 +757,10 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     VF_HIP_TRY(hipStreamWaitEvent(t->side2, S.boxed, 0));               // (orders it after S.drawn and the height cache too)
     // (one short-lived workgroup per possible segment -- those beyond the list's length leave at once: workgroups that come and go
     //  share the CUs with the previous frame's tile kernel more smoothly than a few long-lived ones)
+    // (experiments only, VF_DBG_NO_SETUP=1: a camera at rest re-creates the same records in the same buffers, so after the first frames
+    //  the pass can be left out to see what the frame costs without it -- the picture stays right, the time is a lower bound)
+    static const bool dbg_no_setup = std::getenv("VF_DBG_NO_SETUP") != nullptr;
+    if (!(dbg_no_setup && t->frames_since_reset > 6))
     hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, t->side2,
                        P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen, S.seg_list, seg_count);
     VF_HIP_TRY(hipEventRecord(S.set_up, t->side2));
@@ -722,8 +787,12 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t nstats = (uint32_t)(4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32);   // zeroed by k_clear (no memset dispatch)
     VF_HIP_TRY(hipStreamWaitEvent(s, S.planned, 0));
     VF_HIP_TRY(hipStreamWaitEvent(s, S.set_up, 0));
-    // the previous frame may have been drawn on another stream of the caller's: it wrote the same output / statistics buffers
-    if (t->last_stream && t->last_stream != s && t->rendered) VF_HIP_TRY(hipStreamWaitEvent(s, O.drawn, 0));
+    // The previous frame may have been drawn on another stream of the caller's: this frame waits for it (same output / statistics
+    // buffers; and when it went to another output buffer, letting the two tile kernels overlap costs more than it gains -- the
+    // experiment behind VF_OVERLAP_FRAMES, tools/exp_overlap.py).
+    static const bool overlap_frames = std::getenv("VF_OVERLAP_FRAMES") != nullptr;
+    if (t->last_stream && t->last_stream != s && t->rendered && (!overlap_frames || t->last_out == t->d_rgba || stats || write_vis || !t->last_out))
+        VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
@@ -737,19 +806,58 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
         const bool fast = fast_shading(t);
-        if (write_vis && fast) {
-            hipLaunchKernelGGL((k_tile<true, false, true>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<true, true, true>), few, threads, 0, s, VF_TILE_ARGS);
-        } else if (write_vis) {
-            hipLaunchKernelGGL((k_tile<true, false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<true, true, false>), few, threads, 0, s, VF_TILE_ARGS);
-        } else if (fast) {
-            hipLaunchKernelGGL((k_tile<false, false, true>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<false, true, true>), few, threads, 0, s, VF_TILE_ARGS);
-        } else {
-            hipLaunchKernelGGL((k_tile<false, false, false>), per_cu, threads, 0, s, VF_TILE_ARGS);
-            hipLaunchKernelGGL((k_tile<false, true, false>), few, threads, 0, s, VF_TILE_ARGS);
+        // line groups in the raster's line loop (vf_kernels.h, raster_fast): whole frames and shards of few ranks -- wide items, triangles
+        // with many lines -- gain from them (C4: one GPU -2 %, top-down camera -7 %); a rank of many mostly draws narrow strips, whose
+        // triangles have a handful of lines, and is better off with the leaner kernel (VF_GROUPS=0 / 1 overrides)
+        static const int groups_env = std::getenv("VF_GROUPS") ? std::atoi(std::getenv("VF_GROUPS")) : -1;
+        const int forced = groups_env >= 0 ? groups_env : t->groups_mode;
+        // the variant by default: groups for whole frames and shards of few ranks, none for a rank of many (mostly narrow strips)
+        const int guess = t->nranks < (uint32_t)VF_GROUPS_MAX_RANKS ? 1 : 0;
+        int pick = guess;
+        if (!VF_GROUPED) pick = 0;
+        else if (forced >= 0) pick = forced != 0;
+        else {
+            // probes that have completed (frames behind us: never a wait)
+            for (auto &g : t->gprobe)
+                if (g.pending && hipEventQuery(g.b) == hipSuccess) {
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && ms > 0.0f) { t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(++t->g_n[g.variant]); }
+                    g.pending = false;
+                }
+            (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
+            if (fresh || t->frames_since_reset <= 1) { t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }   // what was measured belongs to another view / layout
+            // the plan settles for a few frames on the default variant; then four frames of each; then the faster one, looked at again now and then
+            const uint32_t e = t->g_epoch_frames++;
+            constexpr uint32_t kSettle = 6, kProbe = 4, kAgain = 256;
+            if (e < kSettle) pick = guess;
+            else if (e < kSettle + kProbe) pick = guess;
+            else if (e < kSettle + 2 * kProbe) pick = !guess;
+            else if (t->g_n[0] && t->g_n[1]) {
+                pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
+                if (e % kAgain == kAgain - 1) pick = !pick;           // (one frame of the other variant -- and the one before it of this -- keeps the times current)
+            }
         }
+        t->groups_now = pick;
+        const bool groups = pick != 0;
+        // timed: the frames of the two probe windows, and now and then one frame of each variant (an event pair costs a marker packet or two)
+        const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
+        const bool probe = VF_GROUPED && forced < 0 && ((e_now >= 6u && e_now < 14u) || e_now % 256u >= 254u);
+        vf_terrain::GroupProbe *gp = nullptr;
+        if (probe) { gp = &t->gprobe[t->gprobe_head++ % 8]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
+        if (gp) VF_HIP_TRY(hipEventRecord(gp->a, s));
+        // (the complete variant redraws the rare items that met a clipped primitive: always the plain loop)
+#define VF_TILE_LAUNCH(WV, FS)                                                                                         \
+        do {                                                                                                           \
+            if (groups) hipLaunchKernelGGL((k_tile<WV, false, FS, true>), per_cu, threads, 0, s, VF_TILE_ARGS);        \
+            else hipLaunchKernelGGL((k_tile<WV, false, FS, false>), per_cu, threads, 0, s, VF_TILE_ARGS);              \
+            if (gp) { (void)hipEventRecord(gp->b, s); gp->variant = groups ? 1 : 0; gp->pending = true; gp = nullptr; } \
+            hipLaunchKernelGGL((k_tile<WV, true, FS, false>), few, threads, 0, s, VF_TILE_ARGS);                       \
+        } while (0)
+        if (write_vis && fast) VF_TILE_LAUNCH(true, true);
+        else if (write_vis) VF_TILE_LAUNCH(true, false);
+        else if (fast) VF_TILE_LAUNCH(false, true);
+        else VF_TILE_LAUNCH(false, false);
+#undef VF_TILE_LAUNCH
 #undef VF_TILE_ARGS
     }
     else VF_HIP_TRY(hipMemsetAsync(seg_count, 0, sizeof(uint32_t), s));   // (a shard without tiles: what k_clear does on its way in)
@@ -757,6 +865,8 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     VF_HIP_TRY(hipEventRecord(S.drawn, s));
     VF_HIP_TRY(hipGetLastError());
     t->last_stream = s;
+    t->last_set = set;
+    t->last_out = t->d_rgba;
     t->rendered = true;
     return VF_OK;
 }
@@ -931,7 +1041,7 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
     VF_HIP_TRY(hipMalloc(&d_out, npx * sizeof(uint32_t)));
     if (!t->d_diag) { hipError_t e = hipMalloc(&t->d_diag, 4 * sizeof(uint32_t)); if (e != hipSuccess) { (void)hipFree(d_out); return fail(VF_ERR_NOMEM, "diagnostics allocation failed"); } }
     uint32_t redo = 0;                                      // did the frame hold clipped / oversized primitives?  (normally not)
-    hipError_t err = hipMemcpy(&redo, t->ps[(t->frame_no - 1u) & 1u].work_count + 3, sizeof redo, hipMemcpyDeviceToHost);
+    hipError_t err = hipMemcpy(&redo, t->ps[t->last_set].work_count + 3, sizeof redo, hipMemcpyDeviceToHost);
     FrameParams P;
     float u_now[44];
     std::memcpy(u_now, t->u, sizeof u_now);
@@ -951,7 +1061,7 @@ int vf_terrain_debug_fragment_stage(vf_terrain *t, uint32_t repeats, vf_fragment
     const uint32_t per_cu = std::getenv("VF_RESOLVE_PER_CU") ? (uint32_t)std::max(1, std::atoi(std::getenv("VF_RESOLVE_PER_CU"))) : (quads ? 3u : 4u);
     const uint32_t cus = (uint32_t)std::max(8, t->ctx->prop.multiProcessorCount) / 8u * 8u;
     const dim3 grid(std::min<uint32_t>((((t->W + 31u) / 32u) * ((t->H + 7u) / 8u) + 7u) / 8u * 8u, cus * per_cu)), threads(256);   // 32 x 8 pixel regions
-    const vf_terrain::PlanState &S = t->ps[(t->frame_no - 1u) & 1u];     // the set-up of the frame just rendered
+    const vf_terrain::PlanState &S = t->ps[t->last_set];     // the set-up of the frame just rendered
     const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
     // four pixels per lane when the rows allow 16-byte accesses and the frame holds no clipped primitive (VF_RESOLVE_PER_PIXEL=1: the per-pixel form)
     constexpr uint32_t RQ = 8u, RY = 32u;                  // k_resolve4's region: 8 quads x 32 rows
@@ -997,7 +1107,7 @@ int vf_terrain_debug_item_stats(vf_terrain *t, uint32_t *dst, uint32_t max_items
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
     uint32_t n = 0;
-    VF_HIP_TRY(hipMemcpy(&n, t->ps[(t->frame_no - 1u) & 1u].work_count, sizeof n, hipMemcpyDeviceToHost));
+    VF_HIP_TRY(hipMemcpy(&n, t->ps[t->last_set].work_count, sizeof n, hipMemcpyDeviceToHost));
     if (n > max_items) n = max_items;
     if (n) VF_HIP_TRY(hipMemcpy(dst, t->d_stats + 4, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *count = n;
@@ -1541,7 +1651,7 @@ int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gat
     ncclComm_t comm = (ncclComm_t)rccl_comm;
     hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
     if (s != t->last_stream && t->last_stream) {            // the slab is being drawn on another stream: order the exchange after it
-        VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+        VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     }
     const size_t tile_bytes = (size_t)kTileW * kTileH * 4;
     const bool is_root = (uint32_t)root == t->rank;
@@ -1588,7 +1698,7 @@ int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_ima
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     ncclComm_t comm = (ncclComm_t)rccl_comm;
     hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
-    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     const bool is_root = (uint32_t)root == t->rank;
     if (is_root && !dev_image) return fail(VF_ERR_INVALID, "the root needs the image buffer");
     const size_t row_bytes = (size_t)t->W * 4;
@@ -1641,7 +1751,7 @@ int vf_dist_exchange_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_i
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     ncclComm_t comm = (ncclComm_t)rccl_comm;
     hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
-    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[(t->frame_no - 1u) & 1u].drawn, 0));
+    if (s != t->last_stream && t->last_stream) VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     const size_t tile_bytes = (size_t)kTileW * kTileH * 4;
     const uint32_t band_tile_rows = t->nty / N, chunk_tiles = band_tile_rows * (t->ntx / N);   // tiles one rank holds of one band
     const size_t chunk_bytes = (size_t)chunk_tiles * tile_bytes;

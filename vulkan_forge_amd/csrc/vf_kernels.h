@@ -196,10 +196,15 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
         if (P.nranks > 1u && r.x0 <= r.x1) {
             bool mine = false;
             if (P.shard_tiles) {
-                const uint32_t tx0 = (uint32_t)r.x0 / kTileW, tx1 = (uint32_t)r.x1 / kTileW, ty0 = (uint32_t)r.y0 / kTileH, ty1 = (uint32_t)r.y1 / kTileH;
-                if (tx1 - tx0 + 1u >= P.nranks) mine = true;             // a full period of tile columns: every rank owns one in each row
+                const uint32_t tx0 = ((uint32_t)r.x0 / kTileW) >> P.stripe_shift, tx1 = ((uint32_t)r.x1 / kTileW) >> P.stripe_shift;     // stripes (groups of tile columns)
+                const uint32_t ty0 = (uint32_t)r.y0 / kTileH, ty1 = (uint32_t)r.y1 / kTileH;
+                if (tx1 - tx0 + 1u >= P.nranks) mine = true;             // a full period of stripes: every rank owns one in each row
+                if (P.stripe_rot) {                                      // (experiments: permuted periods -- test every stripe of the box)
+                    for (uint32_t g = tx0; g <= tx1 && !mine; ++g)
+                        mine = (P.stripe_rot == 1u ? (g + g / P.nranks) % P.nranks : (((g / P.nranks) & 1u) ? P.nranks - 1u - g % P.nranks : g % P.nranks)) == P.rank;
+                } else
                 for (uint32_t ty = ty0; ty <= ty1 && !mine; ++ty) {
-                    // owner(tx, ty) = (tx + skew ty) % nranks: the first column >= tx0 this rank owns in row ty
+                    // owner(tx, ty) = ((tx >> stripe_shift) + skew ty) % nranks: the first stripe >= tx0 this rank owns in row ty
                     const uint32_t want = (P.rank + P.nranks - (P.skew * ty) % P.nranks) % P.nranks;
                     const uint32_t first = tx0 + (want + P.nranks - tx0 % P.nranks) % P.nranks;
                     mine = first <= tx1;
@@ -491,7 +496,18 @@ __device__ __forceinline__ int32_t floor_to_int(float x)
 }
 // `vb` / `vcode`: where the three vertices came from (this wave's LDS copy of the block, local indices v0 | v1 << 8 | v2 << 16): the
 // exact solver reloads them from there instead of keeping six more registers alive through the line loop for a rare event.
-__device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, const int2 *vb, uint32_t vcode, int32_t sub, int32_t nsub VF_RC_ARG)
+// GROUPS (VF_GROUPED, round 4): nineteen lines in twenty end in stage 1 -- their span holds no open pixel -- and a wave walks them at
+// the pace of its busiest lane.  So the lanes of a triangle first test its lines four at a time: one bound for the spans of four
+// adjacent lines (span_group: the same three crossings, taken at the end of the group each edge's slope points away from) against
+// the AND of their four final-pixel masks.  A group without an open pixel inside its bound cannot paint and is dropped; the verdicts
+// travel between the triangle's lanes by ballot, and only the lines of the groups that are left are dealt to the lanes and solved as
+// before.  The pixels painted are the same by construction (a dropped line would have failed its own stage-1 test).
+// `first`: the wave's first lane working on this triangle (lanes first .. first + nsub - 1 do, all of them active here).
+#ifndef VF_GROUPED
+#define VF_GROUPED 1
+#endif
+template <bool GROUPS>
+__device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, const int2 *vb, uint32_t vcode, int32_t sub, int32_t nsub, uint32_t first VF_RC_ARG)
 {
     VF_RC(RC.tris++;)
     int32_t px0, py0, n_outer, n_inner, o_base, i_base;
@@ -513,9 +529,50 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
     o_base = cols ? px0 - T.px_lo : py0 - T.py_lo;         // tile-local index of outer line 0
     i_base = cols ? py0 - T.py_lo : px0 - T.px_lo;         // tile-local index of inner offset 0
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
-    for (int32_t o = sub; o <= n_outer; o += nsub) {
+    // (one loop header or the other: the body below is shared)
+    uint32_t gmask = 0, gleft = 0;
+    int32_t passed = 0, nlines_left = 0;
+    if constexpr (GROUPS) {
+    // ---- stage 0: the groups of four lines, one per lane and trip; every lane of the triangle takes the same trips ----
+    const int32_t ng = (n_outer >> 2) + 1;                 // group g = lines 4 g .. min(4 g + 3, n_outer); at most 16
+    // (a triangle whose lanes have a line or two each gains nothing from the test -- a 4-pixel strip's triangles have four lines in
+    //  all: their groups all count as open, and a wave without any other triangle skips the loop)
+#ifndef VF_GROUP_MIN
+#define VF_GROUP_MIN 2
+#endif
+    const bool test_groups = n_outer + 1 > VF_GROUP_MIN * nsub;
+    gmask = test_groups ? 0u : (1u << ng) - 1u;
+    const uint32_t lanes_mask = nsub >= 32 ? 0xFFFFFFFFu : (1u << nsub) - 1u;
+    for (int32_t kb = 0; test_groups && kb < ng; kb += nsub) {
+        const int32_t g = kb + sub;
+        bool open = false;
+        if (g < ng) {
+            const int32_t oa = 4 * g, ob = min(oa + 3, n_outer);
+            const uint64_t done4 = load_mask(fin, o_base + oa) & load_mask(fin, o_base + min(oa + 1, ob)) & load_mask(fin, o_base + min(oa + 2, ob)) & load_mask(fin, o_base + ob);
+            int32_t glo, ghi;
+            span_group(S, oa, ob, n_inner, glo, ghi);
+            if (!S.regular) { glo = 0; ghi = n_inner; }
+            open = glo <= ghi && (bit_range(i_base + min(glo, n_inner), i_base + max(ghi, 0)) & ~done4) != 0ull;
+            VF_RC(RC.lines += (uint32_t)(ob - oa + 1);)
+        }
+        VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;)
+        const unsigned long long votes = __ballot(open);
+        gmask |= ((uint32_t)(votes >> first) & lanes_mask) << kb;     // (groups beyond ng voted no; other triangles' lanes are masked out)
+    }
+    // ---- the lines of the groups that are left, dealt to the lanes in order ----
+    gleft = gmask;                                         // groups not yet passed by this lane; `passed` of them are behind it
+    nlines_left = 4 * (int32_t)__popc(gmask);
+    }
+    // GROUPS: idx runs over the lines of the open groups; otherwise over all lines (idx = o)
+    for (int32_t idx = sub; GROUPS ? idx < nlines_left : idx <= n_outer; idx += nsub) {
+        int32_t o = idx;
+        if constexpr (GROUPS) {
+            while (passed < (idx >> 2)) { gleft &= gleft - 1u; ++passed; }
+            o = 4 * (int32_t)__builtin_ctz(gleft) + (idx & 3);
+            if (o > n_outer) continue;
+        }
         const uint64_t done = load_mask(fin, o_base + o);
-        VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;)
+        if constexpr (!GROUPS) { VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;) }
         // ---- stage 1 (straight-line): a span that contains the true one; does it hold an open pixel? ----
         int32_t F[3], lo, hi;
         span_line(S, o, n_inner, F, lo, hi);
@@ -1305,7 +1362,10 @@ __global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, co
 // shares the CUs with it).  At that cap it spills 64 bytes per lane (profiles/r03_isa_stats.txt, tools/isa_stats.py): the stores at
 // kernel entry and in the item loop, the reloads in the item and chunk loops -- and ONE reload per pulled block (loop depth 3, the
 // block pull loop); none in pass A, pass B, the line loop or the paint loop.
-template <bool WRITE_VIS, bool COMPLETE, bool FAST>
+// GROUPS: the line loop of raster_fast tests a triangle's lines in groups of four first (above).  A launch-time choice, not a per-item
+// one: both loops in one kernel cost the narrow strips of a multi-GPU rank 6 % (registers: the block loop's spills), so the host picks
+// the instantiation per handle -- whole frames and wide shards with groups, many-rank shards (mostly strips) without (vf_hip.hip).
+template <bool WRITE_VIS, bool COMPLETE, bool FAST, bool GROUPS>
 __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameParams P, SetupView V, const PixelBox *__restrict__ row_boxes,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const float *__restrict__ lut_linear, const float *__restrict__ thresh,
@@ -1398,6 +1458,7 @@ next_item:
     const int32_t tile_x0 = T.px_lo;                       // the tile's left edge (T.px_lo becomes the strip's below)
     work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2..16 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
+
     const uint64_t row_full = ~0ull >> (63 - (T.px_hi - T.px_lo));   // row mask of a fully final row of this tile / strip
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
@@ -1751,7 +1812,7 @@ next_item:
                             const uint32_t va = lj * kBlockVerts + li, vb = va + 1, vc = va + kBlockVerts, vd = vc + 1;
                             const uint32_t v0 = odd ? vb : va, v1 = vc, v2 = odd ? vd : vb;
                             const uint32_t prim = 2u * ((j0 + lj) * P.nm1 + (i0 + li)) + odd;
-                            raster_fast(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)my_sub, (int32_t)my_n VF_RC(, RC));
+                            raster_fast<GROUPS>(T, prim + 1u, sXY[wave], v0 | (v1 << 8) | (v2 << 16), (int32_t)my_sub, (int32_t)my_n, lane - my_sub VF_RC(, RC));
                         }
                         if (balanced) break;
                     }
@@ -1820,6 +1881,9 @@ next_item:
 #endif
 #ifdef VF_DBG_WEIGHT
         stats[5 + 4 * item_idx] = work[item_idx].y;         // (experiment: the plan's weight of the item instead of the block count)
+#endif
+#ifdef VF_DBG_ITEMSTART
+        stats[5 + 4 * item_idx] = (uint32_t)t_start;        // (experiment: when the item started, 10 ns ticks of the 100 MHz clock -- tools/exp_gantt.py)
 #endif
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }

@@ -188,6 +188,31 @@ VF_HD void span_line(const SpanSetup &S, int32_t o, int32_t n_inner, int32_t F[3
     lo = l; hi = h;
 }
 
+// Stage 0 (round 4): one bound for a GROUP of adjacent lines oa .. ob: a span [lo, hi] that contains the stage-1 span of every line of
+// the group -- when it holds no open pixel of any of them, none of those lines can paint and the group is skipped untested.
+// Why it contains them: the stage-1 bounds of line o are built from F_i(o) = floor(med3(fma(o, s_i, km_i))), and both lo (through the
+// lower edges' c_i = F_i + 1) and hi (through the upper edges' -F_i - 1) move the CONSERVATIVE way when F_i is replaced by something
+// smaller.  F_i is monotone in o (the exact o s_i + km_i is, and rounding, med3 and floor keep order), so its minimum over the group
+// is F_i at oa when the stored slope s_i is >= 0 and at ob otherwise: the same instruction sequence as span_line at that end point,
+// bit for bit.  (The per-line test of an edge parallel to the lines is left to span_line: ignoring it here only widens the bound.)
+VF_HD void span_group(const SpanSetup &S, int32_t oa, int32_t ob, int32_t n_inner, int32_t &lo, int32_t &hi)
+{
+    const float fa = (float)oa, fb = (float)ob, w_hi = (float)(n_inner + 4), w_lo = -w_hi;
+    int32_t c[3];
+#if VF_RASTER_DEVICE
+#pragma unroll
+#endif
+    for (int i = 0; i < 3; ++i) {
+        const float of = S.s[i] < 0.0f ? fb : fa;
+        const int32_t F = rs_floor_i(rs_med3(rs_fma(of, S.s[i], S.km[i]), w_lo, w_hi));
+        c[i] = (F ^ S.x[i]) + S.c1[i];
+    }
+    int32_t cmax = c[0] > c[1] ? c[0] : c[1], cmin = c[0] < c[1] ? c[0] : c[1];
+    cmax = cmax > c[2] ? cmax : c[2]; cmin = cmin < c[2] ? cmin : c[2];
+    const int32_t l = cmax > 0 ? cmax : 0, h = cmin + kSpanBig;
+    lo = l; hi = h < n_inner ? h : n_inner;
+}
+
 // Stage 2: true when no pixel centre lies within the FP32 error of any crossing -- the stage-1 span is then the exact one.
 VF_HD bool span_confirm(const SpanSetup &S, int32_t o, int32_t n_inner, const int32_t F[3])
 {
