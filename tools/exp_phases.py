@@ -21,7 +21,8 @@ for cam in ("default", "fill"):
     print(f"{cam}: tile_ms={tm['tile_ms']:.3f} pairs={tm['blocks_rasterised']} wave-cycles total={tot:.3e} (= {tot/16/2.4e6:.1f} ms of workgroup time at 2.4 GHz)")
     for n, c in zip(names, ph):
         print(f"   {n:20s} {100*c/tot:6.2f} %   {c/max(tm['blocks_rasterised'],1):9.0f} cycles/pair")
-    print(f"   line loop, wave-level executions per pair: iterations={wv[0]/live:.2f}  estimate stage={wv[1]/live:.2f}  exact stage={wv[2]/live:.2f}  paint steps={wv[3]/live:.2f};  classification: triangles reaching the occlusion loop={wv[5]/live:.1f}, its wave-level iterations={wv[4]/live:.2f}")
+    use, _ = t.raster_groups()
+    print(f"   line loop ({'with line groups: group-test trips' if use else 'plain: line trips'}={wv[0]/live:.2f}), wave-level executions per pair: lines reaching stage 1={wv[1]/live:.2f}  stage 2={wv[2]/live:.2f}  paint steps={wv[3]/live:.2f};  classification: triangles reaching the occlusion loop={wv[5]/live:.1f}, its wave-level iterations={wv[4]/live:.2f}")
     for n, c in zip(["row list", "candidate tests", "wait for slowest wave", "scan + list fill", "hand-over + pull", "item record + tile state", "row mask", "-"], sub):
         print(f"      set-up: {n:22s} {100*c/tot:6.2f} %")
     print(f"      vertex: record wait {100*vsub[0]/tot:.2f} %  (one empty time stamp: {100*vsub[1]/tot:.2f} % = {vsub[1]/live:.0f} cycles per pair; every phase above holds one per boundary)  staging + alive-list compaction {100*(ph[2]-vsub.sum())/tot:.2f} %")

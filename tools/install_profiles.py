@@ -28,15 +28,20 @@ def last_json_line(path):
     return [l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1]
 
 
+LAUNCHES = collections.Counter()                            # kernel -> launches seen in the pass read last
+
+
 def per_kernel(path, agg_last=None):
     """{(kernel, counter): average per launch} over all launches (or the last `agg_last`)."""
     vals = collections.defaultdict(lambda: collections.OrderedDict())
+    LAUNCHES.clear()
     for r in csv.DictReader(open(path)):
         k = (r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])
         d = int(r["Dispatch_Id"])
         vals[k][d] = vals[k].get(d, 0.0) + float(r["Counter_Value"])
     out = {}
     for k, v in vals.items():
+        LAUNCHES[k[0]] = max(LAUNCHES[k[0]], len(v))
         xs = list(v.values())
         xs = xs[-agg_last:] if agg_last else xs
         out[k] = sum(xs) / len(xs)
@@ -49,12 +54,17 @@ def copy(src, dst):
 
 open(os.path.join(P, f"{prefix}_bench.json"), "w").write(last_json_line(os.path.join(G, "bench.json")) + "\n")
 open(os.path.join(P, f"{prefix}_bench_c5.json"), "w").write(last_json_line(os.path.join(G, "bench_c5.json")) + "\n")
-open(os.path.join(P, f"{prefix}_rehearse_4ranks.json"), "w").write(last_json_line(os.path.join(G, "rehearse_4ranks.json")) + "\n")
+for n in (2, 4):
+    if os.path.exists(os.path.join(G, f"rehearse_{n}ranks.json")):
+        open(os.path.join(P, f"{prefix}_rehearse_{n}ranks.json"), "w").write(last_json_line(os.path.join(G, f"rehearse_{n}ranks.json")) + "\n")
 copy("kernel_stats.csv", "kernel_stats.csv")
 for n in ("fetch_default", "write_default", "frag_fetch_default", "frag_write_default", "frag_fetch_fill", "frag_write_fill", "frag_l1_default", "frag_l1_fill"):
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
 for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log", "rank0_stitch.log", "cold.log", "fragment.log", "parity_soak.log"):
     copy(n, n)
+for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.log", "stripes.log"):      # round 4
+    if os.path.exists(os.path.join(G, n)):
+        copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
 
 # ---- SQ utilisation (default camera) ------------------------------------------------------------------------------------
@@ -62,11 +72,14 @@ sq = {}
 lines = []
 for n in ("sq_a", "sq_b"):
     pk = per_kernel(os.path.join(G, f"pmc_{n}.csv"))
-    lines.append(f"pmc_{n}.csv (averages per launch)")
+    # the frame's main launch exists with and without line groups (round 4; the handle probes both for a few frames): the one that drew most frames
+    mains = [k for k in LAUNCHES if k.startswith("vf::k_tile<false, false")]
+    main = max(mains, key=lambda k: LAUNCHES[k]) if mains else ""
+    lines.append(f"pmc_{n}.csv (averages per launch; main tile kernel of the run: {main}, {LAUNCHES.get(main, 0)} launches)")
     for (kern, ctr), v in sorted(pk.items()):
         if "k_tile" in kern or "k_block_setup" in kern:
-            lines.append(f"  {kern:26s} {ctr:26s} {v:16.0f}")
-        if kern.startswith("vf::k_tile<false, false"):
+            lines.append(f"  {kern:34s} {ctr:26s} {v:16.0f}   ({LAUNCHES[kern]} launches)")
+        if kern == main:
             sq[ctr] = v
 open(os.path.join(P, f"{prefix}_sq_counters.txt"), "w").write("\n".join(lines) + "\n")
 

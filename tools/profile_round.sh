@@ -38,6 +38,13 @@ timeout -k 10 300 python tools/exp_toptiles.py > "$out/top_items.log" 2>&1
 timeout -k 10 300 python tools/exp_rank_frames.py 2 8 > "$out/rank_frames.log" 2>&1; grep period "$out/rank_frames.log"
 echo "== rank 0's stitch"; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 default > "$out/rank0_stitch.log" 2>&1; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 fill >> "$out/rank0_stitch.log" 2>&1; grep period "$out/rank0_stitch.log" | tail -8
 echo "== first frames"; timeout -k 10 200 python tools/exp_cold.py default > "$out/cold.log" 2>&1; timeout -k 10 200 python tools/exp_cold.py fill >> "$out/cold.log" 2>&1; grep rep "$out/cold.log"
-echo "== rehearsal"; timeout -k 10 600 python bench.py --gpus 4 --rehearse --check --no-cpu-baseline --steps 5 > "$out/rehearse_4ranks.json" 2> "$out/rehearse_4ranks.err"; tail -c 300 "$out/rehearse_4ranks.json"
-echo "== soak"; timeout -k 10 400 python tests/soak_parity.py 400000 100000 300 > "$out/parity_soak.log" 2>&1; tail -1 "$out/parity_soak.log"
+echo "== rehearsal"; for n in 2 4; do timeout -k 10 600 python bench.py --gpus $n --rehearse --no-cpu-baseline --steps 5 > "$out/rehearse_${n}ranks.json" 2> "$out/rehearse_${n}ranks.err"; echo "rc=$?"; tail -c 300 "$out/rehearse_${n}ranks.json"; done
+# round 4: where the tile kernel's time goes (build/variants/libvf_phase.so = tools/build_variant.sh phase -DVF_PHASE_PROF), one GPU and a rank of eight;
+# the rank's SQ counters; when each work item starts and ends (libvf_gantt.so = -DVF_DBG_ITEMSTART); which line loop the handle picks per view
+if [ -f build/variants/libvf_phase.so ]; then echo "== phase cycles"; timeout -k 10 200 python tools/exp_phases.py build/variants/libvf_phase.so > "$out/phase_cycles.log" 2>&1; echo "---- rank 2 of 8" >> "$out/phase_cycles.log"; timeout -k 10 200 python tools/exp_phases.py build/variants/libvf_phase.so 2 8 0 >> "$out/phase_cycles.log" 2>&1; grep -c cycles/pair "$out/phase_cycles.log"; fi
+if [ -f build/variants/libvf_gantt.so ]; then echo "== schedule"; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default > "$out/gantt.log" 2>&1; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default 2 8 >> "$out/gantt.log" 2>&1; grep "tile_ms" "$out/gantt.log"; fi
+echo "== rank SQ counters"; tools/pmc_rank.sh $tag/rank_sq 2 8 0 > "$out/rank_sq_counters.txt" 2>&1; tail -4 "$out/rank_sq_counters.txt"
+echo "== line loops"; timeout -k 10 300 python tools/exp_groups_auto.py > "$out/line_loops.log" 2>&1; cat "$out/line_loops.log"
+echo "== stripe widths"; (for sh in 0 1 2; do echo "stripe width $((1<<sh)) tile(s)"; VF_STRIPE_LOG2=$sh timeout -k 10 200 python tools/exp_ranks.py default 1:0 2:0 4:0 8:0; done; echo "stripe width 8 tiles"; VF_STRIPE_LOG2=3 timeout -k 10 200 python tools/exp_ranks.py default 2:0) > "$out/stripes.log" 2>&1; grep -c period "$out/stripes.log"
+echo "== soak"; timeout -k 10 500 python tests/soak_parity.py $((500000 + RANDOM)) 100000 400 > "$out/parity_soak.log" 2>&1; tail -1 "$out/parity_soak.log"
 echo "== done"
