@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--root-stitch", action="store_true",
                     help="N>1: every slab to rank 0, which stitches the whole frame (round 2's exchange) instead of all-to-all + one band "
                          "stitched per rank + in-place band gather")
+    ap.add_argument("--stripe-log2", type=int, default=None,
+                    help="N>1: log2 of the width, in tiles, of the column stripes dealt to the ranks (default: a period of eight tile columns -- "
+                         "4 tiles for 2 ranks, 2 for 4, 1 from 8 on; vulkan_forge_amd/dist.py::default_stripe_log2)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
                          "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
@@ -211,10 +214,12 @@ def main():
         # rehearsal: same exchange code over gloo through host memory (the device slabs are copied out and back in)
         # Default: the stitch is sharded like the rendering (all-to-all, every rank stitches one band, bands gathered in place) when the
         # tile grid divides by the ranks; --root-stitch / --cabi-gather: every slab to rank 0, which stitches the whole frame.
-        banded = vdist.band_exchange_applies(W, H, world) and not args.root_stitch
+        stripe = vdist.default_stripe_log2(world, (W + 63) // 64) if args.stripe_log2 is None else args.stripe_log2
+        banded = vdist.band_exchange_applies(W, H, world, stripe) and not args.root_stitch
         cabi_bands = banded and args.cabi_gather and not args.rehearse     # the same exchange through the library's own RCCL calls
         xdev = "cpu" if args.rehearse else dev
-        ex = vdist.BandStitchExchange(W, H, xdev, depth=depth) if banded else vdist.TileExchange(W, H, xdev, depth=depth)
+        ex = (vdist.BandStitchExchange(W, H, xdev, depth=depth, stripe_log2=stripe) if banded else
+              vdist.TileExchange(W, H, xdev, depth=depth, skew=vdist.layout_code(0, stripe)))
         t.set_tile_shard(rank, world, ex.skew)
         assert t.local_tiles() == len(vdist.tile_layout(W, H, rank, world, ex.skew))
         share = t.local_tiles() / float(((W + 63) // 64) * ((H + 63) // 64))
@@ -265,7 +270,7 @@ def main():
             elif banded:
                 def stitch_band(recv, band, rows):                   # [ranks][chunk] tile slots -> the rows of this rank's band (the C-ABI's kernel)
                     src, dst = (dev_gathered.copy_(recv), dev_band) if args.rehearse else (recv, band)
-                    t.stitch_tiles(src.data_ptr(), dst.data_ptr(), world, 0, ex.chunk_tiles, side.cuda_stream, height=rows)
+                    t.stitch_tiles(src.data_ptr(), dst.data_ptr(), world, ex.skew, ex.chunk_tiles, side.cuda_stream, height=rows)
                     if args.rehearse:
                         side.synchronize()
                         band.copy_(dev_band)
@@ -558,7 +563,7 @@ def main():
             metric = "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})"
             workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
             par = ("1 GPU, whole frame" if world == 1 else
-                   f"64x64 screen tiles interleaved over {world} GPUs (owner = (tx + {ex.skew}*ty) % {world}), " +
+                   f"64x64 screen tiles in column stripes of {1 << (ex.skew >> 16)} tile(s) interleaved over {world} GPUs (owner = ((tx >> {ex.skew >> 16}) + {ex.skew & 0xFFFF}*ty) % {world}), " +
                    ("all-to-all (RCCL through the C-ABI, vf_dist_exchange_bands) + one band stitched per rank + bands gathered in place on rank 0, " if cabi_bands else
                     "all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
                     f"p2p gather to rank 0 ({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, ") +

@@ -284,14 +284,15 @@ int vf_dist_gather_tiles(vf_terrain *t, void *rccl_comm, int root, void *dev_gat
 /* Band shards (vf_terrain_set_shard) -> rank `root`: every band is a contiguous band_h * W * 4-byte slab of the final image,
  * so the root receives each remote band in place in `dev_image` ((H, W, 4), no stitch pass) and copies its own. */
 int vf_dist_gather_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_image, void *stream);
-/* Tile shards in column stripes (vf_terrain_set_tile_shard with skew 0) -> the row-major (H, W, 4) frame in `dev_image` on rank
+/* Tile shards in column stripes (vf_terrain_set_tile_shard with skew 0, any stripe width) -> the row-major (H, W, 4) frame in `dev_image` on rank
  * `root`, with the stitch sharded like the rendering -- no rank copies the whole frame (round 3 measured +40..107 us on the root
  * of eight for a whole-frame stitch, +11 us per rank this way).  One call per frame on every rank, all queued on `stream`:
  *   1. all-to-all (one ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd): the frame is cut into nranks horizontal
  *      bands of whole tile rows; a rank's slab holds the tiles of band b contiguously and sends that chunk to rank b;
  *   2. k_stitch_tiles on the rank's band (H / nranks rows; the root stitches straight into `dev_image`);
  *   3. the bands are contiguous slabs of the frame: one more group moves them to the root in place.
- * Needs W, H multiples of 64 and tile columns / tile rows that divide by nranks (C4: 2, 4, 8 ranks); every rank checks that, the
+ * Needs W, H multiples of 64, tile columns that divide by nranks * stripe width and tile rows that divide by nranks (C4: 2, 4, 8
+ * ranks with stripes of 4, 2, 1 tiles); every rank checks that, the
  * communicator (rank / size == the handle's shard) and `root` before anything is posted, so all ranks fail together.  The
  * receive chunks and (off the root) the band live in the handle and are reused by the next call: calls on one handle are
  * ordered on one stream or by the caller's events.  `dev_image` is ignored off the root.

@@ -134,8 +134,11 @@ def test_tile_shards_double_buffered_exchange(world, W, H):
 def test_tile_layout_properties():
     from vulkan_forge_amd import dist as vdist
     for W, H, n, skew in ((4096, 4096, 8, None), (4096, 4096, 4, None), (1920, 1080, 8, None), (200, 150, 3, None), (64, 64, 2, None), (100, 100, 1, None),
-                          (130, 70, 6, None), (4096, 4096, 8, 3), (1920, 1080, 8, 5), (200, 150, 3, 1)):
+                          (130, 70, 6, None), (4096, 4096, 8, 3), (1920, 1080, 8, 5), (200, 150, 3, 1),
+                          (4096, 4096, 2, vdist.layout_code(0, 2)), (4096, 4096, 4, vdist.layout_code(0, 1)), (1920, 1080, 3, vdist.layout_code(0, 2)),
+                          (700, 300, 2, vdist.layout_code(1, 1))):
         skew = vdist.default_skew(n) if skew is None else skew     # default: column stripes (0); skewed maps stay supported
+        sh, sk = skew >> 16, skew & 0xFFFF                          # the layout word: stripe width 1 << sh tiles, row-to-row shift sk
         ntx, nty = (W + 63) // 64, (H + 63) // 64
         seen = np.full((nty, ntx), -1)
         sizes = []
@@ -143,19 +146,20 @@ def test_tile_layout_properties():
             lay = vdist.tile_layout(W, H, r, n, skew)
             sizes.append(len(lay))
             for tx, ty in lay:
-                assert seen[ty, tx] == -1 and (tx + skew * ty) % n == r
+                assert seen[ty, tx] == -1 and ((tx >> sh) + sk * ty) % n == r
                 seen[ty, tx] = r
             assert [tuple(x) for x in lay] == sorted((tuple(x) for x in lay), key=lambda p: (p[1], p[0]))   # row-major storage order
         assert (seen >= 0).all()
         assert vdist.stride_tiles(W, H, n, skew) == max(sizes)
         if ntx >= n:
-            assert max(sizes) - min(sizes) <= nty                 # balanced to within one tile per tile row
+            assert max(sizes) - min(sizes) <= nty << sh            # balanced to within one stripe per tile row
     assert vdist.default_skew(8) == 0 and vdist.default_skew(3) == 0 and vdist.default_skew(2) == 0
     assert len(vdist.tile_layout(4096, 4096, 3, 8, 3)) == 512
+    assert [vdist.default_stripe_log2(n, 64) for n in (1, 2, 4, 8, 16)] == [0, 2, 1, 0, 0] and vdist.default_stripe_log2(2, 4) == 1
 
 
 # ---- tile shards stitched in parallel: all-to-all + one band per rank + in-place band gather (dist.BandStitchExchange) ----------
-def _band_worker(rank, world, port, W, H, G, q):
+def _band_worker(rank, world, port, W, H, G, q, stripe=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -167,16 +171,17 @@ def _band_worker(rank, world, port, W, H, G, q):
     u = O.default_uniforms(O.KIND_SCENE, W, H)
     h = np.random.default_rng(5).random((24, 24), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
     full, _ = O.render_terrain(u, W, H, G, h, lut)                      # the pixels come from the oracle (no GPU in this tier)
-    assert vdist.band_exchange_applies(W, H, world)
-    ex = vdist.BandStitchExchange(W, H, "cpu", depth=2)
-    lay = vdist.tile_layout(W, H, rank, world, 0)
+    assert vdist.band_exchange_applies(W, H, world, stripe)
+    ex = vdist.BandStitchExchange(W, H, "cpu", depth=2, stripe_log2=stripe)
+    assert ex.skew == vdist.layout_code(0, stripe)
+    lay = vdist.tile_layout(W, H, rank, world, ex.skew)
     assert len(lay) == ex.stride
 
     def stitch(recv, band, rows):                                       # what vf_stitch_tiles_device does for a frame of `rows` rows
         img = band.numpy()
         for r in range(world):
             slab = recv[r].numpy().view(np.uint8).reshape(-1, 64, 64, 4)
-            for k, (tx, ty) in enumerate(vdist.tile_layout(W, rows, r, world, 0)):
+            for k, (tx, ty) in enumerate(vdist.tile_layout(W, rows, r, world, ex.skew)):
                 img[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64] = slab[k]
 
     image = torch.zeros((H, W, 4), dtype=torch.uint8) if rank == 0 else None
@@ -197,13 +202,13 @@ def _band_worker(rank, world, port, W, H, G, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H", [(2, 256, 128), (4, 256, 256)])
-def test_tile_shards_band_stitch_exchange(world, W, H):
+@pytest.mark.parametrize("world,W,H,stripe", [(2, 256, 128, 0), (4, 256, 256, 0), (2, 512, 128, 2), (4, 512, 256, 1)])
+def test_tile_shards_band_stitch_exchange(world, W, H, stripe):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, 32, q)) for r in range(world)]
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, 32, q, stripe)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -216,3 +221,4 @@ def test_band_exchange_applicability():
     from vulkan_forge_amd import dist as vdist
     assert vdist.band_exchange_applies(4096, 4096, 8) and vdist.band_exchange_applies(4096, 4096, 2) and vdist.band_exchange_applies(4096, 4096, 4)
     assert not vdist.band_exchange_applies(1920, 1080, 8) and not vdist.band_exchange_applies(4096, 4096, 3) and not vdist.band_exchange_applies(200, 150, 2)
+    assert vdist.band_exchange_applies(4096, 4096, 2, 2) and vdist.band_exchange_applies(4096, 4096, 4, 1) and not vdist.band_exchange_applies(256, 256, 2, 2)

@@ -66,18 +66,20 @@ assert hip.hipMemcpy(out.ctypes.data, image, W * H * 4, 2) == 0
 assert np.array_equal(out, whole)
 # ---- column stripes -> all-to-all + band stitch + in-place band gather (vf_dist_exchange_bands), on a frame of whole tiles ----
 t.close()
-W2, H2 = 960, 640
+W2, H2 = 1024, 640
 u2 = np.load(os.environ["VF_UNIFORMS2"])
 t = cabi.Terrain(W2, H2, G, luts["viridis"]); t.set_height(h); t.set_uniforms(u2)
 t.render(); whole2 = t.read_rgba()
 slab2, image2 = dmalloc((W2 // 64) * (H2 // 64) * 16384), dmalloc(W2 * H2 * 4)
-t.set_tile_shard(0, 1, 0); t.set_output_device(slab2)
+t.set_output_device(slab2)
 out2 = np.empty((H2, W2, 4), np.uint8)
-for rep in range(3):                                        # the handle's staging buffers are reused
+for rep, layout in enumerate((0, 0, 0, 1 << 16)):           # the handle's staging buffers are reused; last: stripes of two tiles (layout word)
+    t.set_tile_shard(0, 1, layout)
     assert hip.hipMemset(image2, 0, W2 * H2 * 4) == 0
     t.render(); t.dist_exchange_bands(comm, 0, image2); t.sync()
     assert hip.hipMemcpy(out2.ctypes.data, image2, W2 * H2 * 4, 2) == 0
     assert np.array_equal(out2, whole2), rep
+t.set_tile_shard(0, 1, 0); t.render()
 assert t.dist_version() > 20000
 # argument checks, made on every rank before anything is posted: wrong root, a skewed shard, a frame that cuts tiles
 try: t.dist_exchange_bands(comm, 1, image2); raise SystemExit("expected an error")
@@ -102,7 +104,7 @@ def test_rccl_gather_through_the_c_abi(oracle, tmp_path):
     upath = tmp_path / "u.npy"
     np.save(upath, oracle.look_at_uniforms(1, 1000, 700, *FILL_CAMERA))
     upath2 = tmp_path / "u2.npy"
-    np.save(upath2, oracle.look_at_uniforms(1, 960, 640, *FILL_CAMERA))
+    np.save(upath2, oracle.look_at_uniforms(1, 1024, 640, *FILL_CAMERA))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VF_ROOT=root, VF_UNIFORMS=str(upath), VF_UNIFORMS2=str(upath2))
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "CABI GATHER OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

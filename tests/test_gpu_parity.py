@@ -263,7 +263,8 @@ def test_c4_full_size_properties(c4, oracle, cam):
         assert np.array_equal(out, a), (nranks, band)
     # interleaved-tile shards (the bench's N > 1 layout): every rank's tile-major slab, placed by vf_tile_layout
     from vulkan_forge_amd import cabi as _cabi
-    for nranks, skew in ((2, 1), (8, 3), (3, 5), (2, 0), (4, 0), (8, 0)):     # skew 0 (column stripes) is the bench's default N > 1 layout
+    # skew 0 (column stripes) is the bench's N > 1 layout: single tile columns for 8 ranks, stripes of 2 tiles for 4, of 4 tiles for 2
+    for nranks, skew in ((2, 1), (8, 3), (3, 5), (2, 0), (4, 0), (8, 0), (2, 2 << 16), (4, 1 << 16), (3, (1 << 16) | 2)):
         out = np.zeros_like(a)
         for r in range(nranks):
             t.set_tile_shard(r, nranks, skew)
@@ -610,7 +611,7 @@ def test_fast_precision_shards_equal_the_whole_frame(cabi, oracle, luts, seed):
                     t.render()
                 out[np.flatnonzero(((np.arange(H) // band) % n) == r)] = t.read_rgba()
             assert np.array_equal(out, whole), (n, band)
-        for n, skew in ((2, 0), (4, 0), (8, 0), (3, 5)):
+        for n, skew in ((2, 0), (4, 0), (8, 0), (3, 5), (2, 2 << 16), (4, 1 << 16)):
             out = np.zeros_like(whole)
             for r in range(n):
                 t.set_tile_shard(r, n, skew)
@@ -660,7 +661,7 @@ t.close()
 W, H, G = 200, 150, 48
 u = oracle.default_uniforms(1, W, H)
 ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
-for nr, skew in ((3, 5), (2, 1), (5, 3)):
+for nr, skew in ((3, 5), (2, 1), (5, 3), (2, 1 << 16), (3, (1 << 16) | 1), (2, 2 << 16)):     # (the last ones: stripes of 2 / 4 tiles -- the layout word skew | stripe_log2 << 16)
     t = cabi.Terrain(W, H, G, lut)
     t.set_uniforms(u); t.set_height_device(d_h.data_ptr(), 64, 64); t.set_shade_precision(0)
     stride = max(len(cabi.tile_layout(W, H, r, nr, skew, lib=t.lib)) for r in range(nr)) + 1     # a stride larger than needed is fine

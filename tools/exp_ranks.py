@@ -1,5 +1,6 @@
 """Steady-state frame period of every rank of an N-GPU tile shard, one rank after another on this GPU (frames rendered back to back, wall
-clock over 40 frames): max over ranks ~ the parallel frame time without the exchange.  usage: exp_ranks.py [camera] [N:skew ...]"""
+clock over 40 frames): max over ranks ~ the parallel frame time without the exchange.  usage: exp_ranks.py [camera] [N:skew[:stripe_log2] ...]
+(stripe_log2 "d" = the default of vulkan_forge_amd/dist.py::default_stripe_log2: a period of eight tile columns)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,17 +12,23 @@ W = H = G = 4096
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, vf.colormap_rgba8("viridis")); t.set_height(h)
 cam = sys.argv[1] if len(sys.argv) > 1 else "default"
-layouts = [tuple(int(v) for v in a.split(":")) for a in sys.argv[2:]] or [(1, 1), (2, 1), (4, 3), (8, 3), (8, 0), (8, 1)]
+from vulkan_forge_amd import dist as vdist
+def parse(a):
+    f = a.split(":")
+    n, skew = int(f[0]), int(f[1])
+    sh = 0 if len(f) < 3 else (vdist.default_stripe_log2(n, W // 64) if f[2] == "d" else int(f[2]))
+    return n, skew, sh
+layouts = [parse(a) for a in sys.argv[2:]] or [(1, 0, 0), (2, 0, 2), (4, 0, 1), (8, 0, 0), (8, 3, 0)]
 t.set_uniforms(b.camera_uniforms(cam, W, H))
 base = None
-for n, skew in layouts:
+for n, skew, sh in layouts:
     per = []
     for r in range(n):
         if n == 1: t.set_shard(0, 1, 64)
-        else: t.set_tile_shard(r, n, skew)
+        else: t.set_tile_shard(r, n, vdist.layout_code(skew, sh))
         for _ in range(30): t.render()
         t.sync(); t0 = time.perf_counter()
         for _ in range(40): t.render()
         t.sync(); per.append((time.perf_counter() - t0) / 40 * 1e3)
     if n == 1: base = per[0]
-    print(f"{cam:8s} N={n} skew={skew}: frame period per rank max {max(per):.3f} min {min(per):.3f} ms" + (f"  -> {base / max(per):.2f}x one GPU (compute only)" if base and n > 1 else ""), flush=True)
+    print(f"{cam:8s} N={n} skew={skew} stripes of {1 << sh}: frame period per rank max {max(per):.3f} min {min(per):.3f} ms" + (f"  -> {base / max(per):.2f}x one GPU (compute only)" if base and n > 1 else ""), flush=True)

@@ -32,7 +32,7 @@ for cam in default fill; do      # the fragment stage alone (k_resolve4), one ca
   pmc frag_l1_$cam "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" "$R/tools/exp_fragment.py" $cam || exit 1
 done
 echo "== fragment stage"; timeout -k 10 120 python tools/exp_fragment.py both > "$out/fragment.log" 2>&1; VF_RESOLVE_PER_PIXEL=1 timeout -k 10 120 python tools/exp_fragment.py both >> "$out/fragment.log" 2>&1; timeout -k 10 120 python tools/exp_fragment.py both exact >> "$out/fragment.log" 2>&1; cat "$out/fragment.log"
-echo "== ranks"; timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0 4:0 8:0 8:3 > "$out/ranks.log" 2>&1; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0 4:0 8:0 8:3 >> "$out/ranks.log" 2>&1; cat "$out/ranks.log"
+echo "== ranks"; timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0:d 4:0:d 8:0:d 8:3 > "$out/ranks.log" 2>&1; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0:d 4:0:d 8:0:d 8:3 >> "$out/ranks.log" 2>&1; cat "$out/ranks.log"
 tools/prof_rank.sh $tag/rank_trace 2 8 0 > "$out/rank_timeline.log" 2>&1; tail -3 "$out/rank_timeline.log"
 timeout -k 10 300 python tools/exp_toptiles.py > "$out/top_items.log" 2>&1
 timeout -k 10 300 python tools/exp_rank_frames.py 2 8 > "$out/rank_frames.log" 2>&1; grep period "$out/rank_frames.log"
@@ -45,6 +45,6 @@ if [ -f build/variants/libvf_phase.so ]; then echo "== phase cycles"; timeout -k
 if [ -f build/variants/libvf_gantt.so ]; then echo "== schedule"; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default > "$out/gantt.log" 2>&1; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default 2 8 >> "$out/gantt.log" 2>&1; grep "tile_ms" "$out/gantt.log"; fi
 echo "== rank SQ counters"; tools/pmc_rank.sh $tag/rank_sq 2 8 0 > "$out/rank_sq_counters.txt" 2>&1; tail -4 "$out/rank_sq_counters.txt"
 echo "== line loops"; timeout -k 10 300 python tools/exp_groups_auto.py > "$out/line_loops.log" 2>&1; cat "$out/line_loops.log"
-echo "== stripe widths"; (for sh in 0 1 2; do echo "stripe width $((1<<sh)) tile(s)"; VF_STRIPE_LOG2=$sh timeout -k 10 200 python tools/exp_ranks.py default 1:0 2:0 4:0 8:0; done; echo "stripe width 8 tiles"; VF_STRIPE_LOG2=3 timeout -k 10 200 python tools/exp_ranks.py default 2:0) > "$out/stripes.log" 2>&1; grep -c period "$out/stripes.log"
+echo "== stripe widths"; (timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0:0 2:0:1 2:0:2 2:0:3 4:0:0 4:0:1 4:0:2 8:0:0 8:0:1 8:0:2; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0:0 2:0:2 4:0:0 4:0:1 8:0:0 8:0:1) > "$out/stripes.log" 2>&1; grep -c period "$out/stripes.log"
 echo "== soak"; timeout -k 10 500 python tests/soak_parity.py $((500000 + RANDOM)) 100000 400 > "$out/parity_soak.log" 2>&1; tail -1 "$out/parity_soak.log"
 echo "== done"

@@ -212,6 +212,7 @@ class Terrain:
         self._check(self.lib.vf_terrain_set_shard(self.t, rank, nranks, band_h))
 
     def set_tile_shard(self, rank, nranks, skew=3):
+        """`skew`: the layout word skew | stripe_log2 << 16 (include/vf_hip.h, VF_TILE_LAYOUT)."""
         self._check(self.lib.vf_terrain_set_tile_shard(self.t, rank, nranks, skew))
 
     def local_tiles(self):

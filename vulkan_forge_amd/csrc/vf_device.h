@@ -60,8 +60,7 @@ struct FrameParams {
     uint32_t local_rows;
     uint32_t shard_tiles;           // 0: whole frame / row bands (local rows, row-major); 1: interleaved tiles (tile-major)
     uint32_t skew;                  // shard_tiles: tile (tx, ty) belongs to rank ((tx >> stripe_shift) + skew * ty) % nranks
-    uint32_t stripe_rot;            // experiments (VF_STRIPE_ROT): 1 = every period of stripes shifted by one rank, 2 = every other period reversed
-    uint32_t stripe_shift;          // log2 of the stripe width in tiles (0: single tile columns; experiments: VF_STRIPE_LOG2)
+    uint32_t stripe_shift;          // log2 of the stripe width in tiles (0: single tile columns)
     const uint32_t *tile_map;       // shard_tiles: local tile -> tx | ty << 16
     uint32_t clear_rgba;            // packed sRGB8 clear colour
     uint32_t shade_mode;            // 0 REFERENCE (terrain.wgsl as coded), 1 SPEC_T32 (the documented fragment stage)

@@ -61,21 +61,10 @@ const SrgbTables &tables()
 }
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
-// (experiments only: VF_STRIPE_LOG2 = log2 of the width, in tiles, of the column stripes a tile shard deals to the ranks; the stitch
-//  kernels and the exchange know single-tile stripes only -- tools/exp_ranks.py measures the rendering side)
-uint32_t stripe_rot() { static const uint32_t v = std::getenv("VF_STRIPE_ROT") ? (uint32_t)std::atoi(std::getenv("VF_STRIPE_ROT")) : 0u; return v; }
-uint32_t stripe_owner(uint32_t g, uint32_t ty, uint32_t skew, uint32_t nranks)
-{
-    const uint32_t rot = stripe_rot();
-    if (rot == 1u) return (g + g / nranks + skew * ty) % nranks;                       // every period of stripes shifted by one rank
-    if (rot == 2u) return (((g / nranks) & 1u) ? nranks - 1u - g % nranks : g % nranks);   // every other period reversed
-    return (g + skew * ty) % nranks;
-}
-uint32_t stripe_shift()
-{
-    static const uint32_t v = [] { const char *e = std::getenv("VF_STRIPE_LOG2"); return e ? (uint32_t)std::min(std::max(std::atoi(e), 0), 4) : 0u; }();
-    return v;
-}
+// Tile-shard layouts are passed as one word, `skew | stripe_log2 << 16` (include/vf_hip.h, VF_TILE_LAYOUT): tile (tx, ty) belongs
+// to rank ((tx >> stripe_log2) + skew * ty) % nranks.
+uint32_t layout_skew(uint32_t layout) { return layout & 0xFFFFu; }
+uint32_t layout_shift(uint32_t layout) { return (layout >> 16) & 0xFu; }
 uint32_t ilog2(uint32_t v)
 {
     uint32_t s = 0;
@@ -560,7 +549,7 @@ int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nran
     uint32_t n = 0;
     for (uint32_t ty = 0; ty < nty; ++ty)
         for (uint32_t tx = 0; tx < ntx; ++tx)
-            if (stripe_owner(tx >> stripe_shift(), ty, skew, nranks) == rank) {
+            if (((tx >> layout_shift(skew)) + layout_skew(skew) * ty) % nranks == rank) {
                 if (tiles && n < capacity) tiles[n] = tx | (ty << 16);
                 ++n;
             }
@@ -653,7 +642,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.W = t->W; P.H = t->H; P.ntx = t->ntx; P.nty = t->nty; P.tw = t->tw; P.th = t->th;
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
-    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = t->skew; P.stripe_shift = stripe_shift(); P.stripe_rot = stripe_rot();
+    P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = layout_skew(t->skew); P.stripe_shift = layout_shift(t->skew);
     P.shade_mode = t->shade_mode; P.tex = t->d_height;
     P.inv2hr = 1.0f / (2.0f * P.h_range);
     {   // cell / nm1 as mulhi(cell, m) >> s, exact for cell < 2^26 (nm1 < 2^13): s = 31 + ceil(log2 nm1) - 32, m = ceil(2^(s + 32) / nm1)
@@ -1516,7 +1505,7 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     uint32_t wgs = (uint32_t)std::max(1, ctx->prop.multiProcessorCount);
     if (const char *e = std::getenv("VF_STITCH_WGS")) wgs = (uint32_t)std::max(1, std::atoi(e));
     hipLaunchKernelGGL(k_stitch_tiles, dim3(std::min(ntx * nty, wgs)), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
-                       ntx, nty, nranks, skew, stride_tiles);
+                       ntx, nty, nranks, layout_skew(skew), layout_shift(skew), stride_tiles);
     VF_HIP_TRY(hipGetLastError());
     return VF_OK;
 }
@@ -1748,9 +1737,9 @@ int vf_dist_exchange_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_i
     if (rc != VF_OK) return rc;
     const uint32_t N = t->nranks;
     // every rank can check the layout for itself, before anything is posted: all ranks fail together
-    if (t->skew != 0u) return fail(VF_ERR_INVALID, "the band exchange needs column stripes (tile shard with skew 0)");
-    if (t->W % (uint32_t)kTileW || t->H % (uint32_t)kTileH || t->ntx % N || t->nty % N)
-        return fail(VF_ERR_INVALID, "the band exchange needs whole tiles and tile columns / tile rows that divide by the number of ranks");
+    if (layout_skew(t->skew) != 0u) return fail(VF_ERR_INVALID, "the band exchange needs column stripes (tile shard with skew 0)");
+    if (t->W % (uint32_t)kTileW || t->H % (uint32_t)kTileH || t->ntx % (N << layout_shift(t->skew)) || t->nty % N)
+        return fail(VF_ERR_INVALID, "the band exchange needs whole tiles, stripes that divide the tile columns evenly among the ranks and tile rows that divide by the number of ranks");
     const bool is_root = (uint32_t)root == t->rank;
     if (is_root && !dev_image) return fail(VF_ERR_INVALID, "the root needs the image buffer");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
@@ -1796,7 +1785,7 @@ int vf_dist_exchange_bands(vf_terrain *t, void *rccl_comm, int root, void *dev_i
     // 2. every rank stitches ITS band (a frame of H / N rows whose tile (tx, ty) sits in slot [tx % N][ty * (ntx / N) + tx / N]):
     //    1 / N of the copy each; the root writes its band straight into the image
     uint8_t *const band = is_root ? (uint8_t *)dev_image + (size_t)t->rank * band_bytes : t->d_xband;
-    rc = vf_stitch_tiles_device(t->ctx, t->d_xrecv, band, t->W, band_rows, N, 0u, chunk_tiles, s);
+    rc = vf_stitch_tiles_device(t->ctx, t->d_xrecv, band, t->W, band_rows, N, t->skew, chunk_tiles, s);
     if (rc != VF_OK) return rc;
     // 3. the bands are contiguous slabs of the final image: the root receives them in place
     if (N > 1u) {

@@ -199,10 +199,6 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
                 const uint32_t tx0 = ((uint32_t)r.x0 / kTileW) >> P.stripe_shift, tx1 = ((uint32_t)r.x1 / kTileW) >> P.stripe_shift;     // stripes (groups of tile columns)
                 const uint32_t ty0 = (uint32_t)r.y0 / kTileH, ty1 = (uint32_t)r.y1 / kTileH;
                 if (tx1 - tx0 + 1u >= P.nranks) mine = true;             // a full period of stripes: every rank owns one in each row
-                if (P.stripe_rot) {                                      // (experiments: permuted periods -- test every stripe of the box)
-                    for (uint32_t g = tx0; g <= tx1 && !mine; ++g)
-                        mine = (P.stripe_rot == 1u ? (g + g / P.nranks) % P.nranks : (((g / P.nranks) & 1u) ? P.nranks - 1u - g % P.nranks : g % P.nranks)) == P.rank;
-                } else
                 for (uint32_t ty = ty0; ty <= ty1 && !mine; ++ty) {
                     // owner(tx, ty) = ((tx >> stripe_shift) + skew ty) % nranks: the first stripe >= tx0 this rank owns in row ty
                     const uint32_t want = (P.rank + P.nranks - (P.skew * ty) % P.nranks) % P.nranks;
@@ -2377,23 +2373,27 @@ __global__ __launch_bounds__(256) void k_png_filter(const uint32_t *__restrict__
 // runs on a side stream BESIDE the next frame's tile kernel, whose 1024-thread workgroups need most of a CU to start -- a launch of
 // one workgroup per tile fills every CU's wave slots and holds them back until it has drained (a rank of eight, emulated: frame
 // period +80 us instead of the +35 the copy is worth).
+// tiles of the stripes a rank owns in one tile row that lie left of column `tx_end`: the owned stripes are g = want, want + nranks, ...
+// (g = tx >> shift), each 1 << shift tiles wide
+__device__ __forceinline__ uint32_t owned_left_of(uint32_t tx_end, uint32_t want, uint32_t nranks, uint32_t shift)
+{
+    const uint32_t g_end = tx_end >> shift, rem = tx_end & ((1u << shift) - 1u);
+    const uint32_t full = g_end > want ? (g_end - 1u - want) / nranks + 1u : 0u;          // owned stripes wholly left of tx_end
+    return (full << shift) + (g_end % nranks == want ? rem : 0u);
+}
 __global__ __launch_bounds__(256) void k_stitch_tiles(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t W, uint32_t H,
-                                                      uint32_t ntx, uint32_t nty, uint32_t nranks, uint32_t skew, uint32_t stride_tiles)
+                                                      uint32_t ntx, uint32_t nty, uint32_t nranks, uint32_t skew, uint32_t shift, uint32_t stride_tiles)
 {
     __shared__ uint32_t s_local;
     const bool wide = (W & 3u) == 0u && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0u;
     for (uint32_t tile = blockIdx.x; tile < ntx * nty; tile += gridDim.x) {
         const uint32_t tx = tile % ntx, ty = tile / ntx;
-        const uint32_t r = (tx + skew * ty) % nranks;
+        const uint32_t r = ((tx >> shift) + skew * ty) % nranks;
         __syncthreads();                                   // (the previous tile's s_local has been read)
         if (threadIdx.x == 0) {
             uint32_t before = 0;                           // tiles of rank r in the rows above
-            for (uint32_t t = 0; t < ty; ++t) {
-                const uint32_t first = (r + nranks - (skew * t) % nranks) % nranks;
-                before += first < ntx ? (ntx - 1u - first) / nranks + 1u : 0u;
-            }
-            const uint32_t first = (r + nranks - (skew * ty) % nranks) % nranks;
-            s_local = before + (tx - first) / nranks;
+            for (uint32_t t = 0; t < ty; ++t) before += owned_left_of(ntx, (r + nranks - (skew * t) % nranks) % nranks, nranks, shift);
+            s_local = before + owned_left_of(tx, (r + nranks - (skew * ty) % nranks) % nranks, nranks, shift);
         }
         __syncthreads();
         const uint32_t *tp = src + ((size_t)r * stride_tiles + s_local) * (kTileW * kTileH);

@@ -86,6 +86,25 @@ def default_skew(nranks: int) -> int:
     return 0
 
 
+def layout_code(skew: int = 0, stripe_log2: int = 0) -> int:
+    """The layout word the C-ABI takes as `skew` (VF_TILE_LAYOUT): tile (tx, ty) -> rank ((tx >> stripe_log2) + skew * ty) % nranks."""
+    return int(skew) | (int(stripe_log2) << 16)
+
+
+def default_stripe_log2(nranks: int, ntx: int = 0) -> int:
+    """log2 of the width, in tiles, of the column stripes dealt to the ranks: a period of eight tile columns -- stripes of 4 tiles for 2
+    ranks, 2 for 4, 1 from 8 ranks on (C4, frame period of the slowest rank against one GPU: 2 ranks 1.55 -> 1.68x, 4 ranks 2.47 ->
+    2.63x; with 8 ranks wider stripes lose, 3.7 -> 3.6x: profiles/r04_stripes.log).  A wider stripe keeps more of a block's tall, narrow
+    footprint inside one rank (fewer blocks set up and drawn by several ranks); a narrower one spreads the silhouette's heavy tiles
+    better.  `ntx` (tile columns of the frame), when given, caps the width so that every rank still owns a stripe."""
+    sh = 2 if nranks <= 2 else 1 if nranks <= 4 else 0
+    if nranks <= 1:
+        return 0
+    while sh > 0 and ntx and (nranks << sh) > ntx:
+        sh -= 1
+    return sh
+
+
 def tile_layout(width: int, height: int, rank: int, nranks: int, skew: int):
     """(n, 2) array of (tx, ty): the tiles of `rank` in storage order (the library's vf_tile_layout; host arithmetic)."""
     from . import cabi
@@ -147,10 +166,11 @@ class TileExchange:
 
 
 # ---- tile shards, stitched in parallel: all-to-all + per-rank band stitch + in-place band gather ------------------------
-def band_exchange_applies(width: int, height: int, nranks: int) -> bool:
-    """`BandStitchExchange` needs column stripes that divide evenly and bands of whole tile rows: ntx and nty multiples of nranks."""
+def band_exchange_applies(width: int, height: int, nranks: int, stripe_log2: int = 0) -> bool:
+    """`BandStitchExchange` needs column stripes that divide evenly and bands of whole tile rows: ntx a multiple of nranks * stripe width,
+    nty a multiple of nranks."""
     ntx, nty = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
-    return nranks >= 1 and width % TILE == 0 and height % TILE == 0 and ntx % nranks == 0 and nty % nranks == 0
+    return nranks >= 1 and width % TILE == 0 and height % TILE == 0 and ntx % (nranks << stripe_log2) == 0 and nty % nranks == 0
 
 
 class BandStitchExchange:
@@ -170,15 +190,15 @@ class BandStitchExchange:
     Double-buffered like `TileExchange`; `stitch(recv, band_image, band_rows)` is the caller's (the C-ABI's stitch kernel on the
     GPU, NumPy in the CPU tests).  Works on CUDA tensors with nccl (RCCL) and on CPU tensors with gloo."""
 
-    def __init__(self, width, height, device, depth=2, dst=0, group=None):
+    def __init__(self, width, height, device, depth=2, dst=0, group=None, stripe_log2=0):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.torch = dist, group, dst, torch
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if not band_exchange_applies(width, height, self.world):
-            raise ValueError("BandStitchExchange needs tile columns and tile rows that divide by the number of ranks")
-        self.W, self.H, self.skew, self.depth = width, height, 0, depth
+        if not band_exchange_applies(width, height, self.world, stripe_log2):
+            raise ValueError("BandStitchExchange needs stripes that divide the tile columns evenly among the ranks and tile rows that divide by their number")
+        self.W, self.H, self.skew, self.depth = width, height, layout_code(0, stripe_log2), depth     # `skew`: the layout word (column stripes)
         ntx, nty = width // TILE, height // TILE
         self.band_rows = height // self.world                         # pixel rows per band
         self.chunk_tiles = (nty // self.world) * (ntx // self.world)  # tiles one rank holds of one band
