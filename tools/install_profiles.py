@@ -88,16 +88,23 @@ data = json.load(open(path)) if os.path.exists(path) else {}
 frame = ["vf::k_block_boxes", "vf::k_block_setup", "vf::k_plan", "vf::k_plan_sort", "vf::k_clear", "vf::k_tile"]
 for cam in ("default", "fill"):
     f = per_kernel(os.path.join(G, f"pmc_fetch_{cam}.csv"), agg_last=3)
+    lf = dict(LAUNCHES)
     w = per_kernel(os.path.join(G, f"pmc_write_{cam}.csv"), agg_last=3)
+    lw = dict(LAUNCHES)
 
-    def fold(d, ctr):
-        """the tile kernel runs as two launches (fast variant, then the complete variant for items it handed over): one entry"""
+    def fold(d, ctr, launches):
+        """the tile kernel runs as two launches (main variant, then the complete variant for items it handed over): one entry.  The main
+        launch exists with and without line groups (round 4; a handle probes both for a few frames): only the one that drew most frames counts"""
+        mains = [k for k in launches if k.startswith("vf::k_tile<false, false")]
+        main = max(mains, key=lambda k: launches[k]) if mains else None
         out = collections.defaultdict(float)
         for (k, c), v in d.items():
             if c == ctr:
+                if k.startswith("vf::k_tile<false, false") and k != main:
+                    continue
                 out["vf::k_tile" if k.startswith("vf::k_tile<false") else k] += v
         return out
-    f, w = fold(f, "FETCH_SIZE"), fold(w, "WRITE_SIZE")
+    f, w = fold(f, "FETCH_SIZE", lf), fold(w, "WRITE_SIZE", lw)
     tile_f, tile_w = f.get("vf::k_tile", 0.0), w.get("vf::k_tile", 0.0)
     entry = {
         "tag": prefix, "lib_sha256": lib_hash,
