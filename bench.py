@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SETTLE = 24                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, then the handle probes its two line loops (frames 10..17)
+SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, the handle probes its two line loops (frames 6..13)
 
 
 def parse():

@@ -819,11 +819,11 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
                 }
             (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
             if (fresh || t->frames_since_reset <= 1) { t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }   // what was measured belongs to another view / layout
-            // the plan settles for some frames on the default variant; then eight frames AABBAABB -- interleaved, so that what is left of the
+            // the plan settles for six frames on the default variant; then eight frames AABBAABB -- interleaved, so that what is left of the
             // plan's settling, and the two plan states the frames alternate between, weigh on both alike; then the faster one, looked at
             // again now and then
             const uint32_t e = t->g_epoch_frames++;
-            constexpr uint32_t kSettle = 10, kProbe = 8, kAgain = 256;
+            constexpr uint32_t kSettle = 6, kProbe = 8, kAgain = 256;
             if (e < kSettle) pick = guess;
             else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) >> 1) & 1u);
             else if (t->g_n[0] && t->g_n[1]) {
@@ -835,7 +835,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         const bool groups = pick != 0;
         // timed: the frames of the two probe windows, and now and then one frame of each variant (an event pair costs a marker packet or two)
         const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
-        const bool probe = VF_GROUPED && forced < 0 && ((e_now >= 10u && e_now < 18u) || e_now % 256u >= 254u);
+        const bool probe = VF_GROUPED && forced < 0 && ((e_now >= 6u && e_now < 14u) || e_now % 256u >= 254u);
         vf_terrain::GroupProbe *gp = nullptr;
         if (probe) { gp = &t->gprobe[t->gprobe_head++ % 8]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
         if (gp) VF_HIP_TRY(hipEventRecord(gp->a, s));
