@@ -1505,8 +1505,9 @@ next_item:
     uint32_t dbg_loop = 0;
 #endif
     const uint32_t hit_words = (P.nb + 63u) / 64u;
-    volatile uint32_t *v_pending = s_pending;
-    volatile uint32_t *v_frontier = &s_frontier, *v_published = &s_published;
+    // (the frontier words are read while other waves write them: relaxed atomic loads on the LDS variables themselves -- a `volatile`
+    //  pointer loses the address space, the loads become FLAT ones and their 64-bit generic addresses live in (spilled) vector registers)
+    auto lds_peek = [](const uint32_t *p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     // a depth slice draws its part of the row list (the complete variant redraws the whole strip, whichever slice filed it)
 #if VF_SLICES
@@ -1826,9 +1827,9 @@ next_item:
             if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
             got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             if (!got) { VF_PH(5) continue; }                           // somebody else is publishing; masks may lag, never lie
-            uint32_t fr = *v_frontier;
-            while (fr < nsteps && v_pending[fr] == 0u) ++fr;
-            const uint32_t pub = *v_published;
+            uint32_t fr = lds_peek(&s_frontier);
+            while (fr < nsteps && lds_peek(&s_pending[fr]) == 0u) ++fr;
+            const uint32_t pub = lds_peek(&s_published);
             if (fr > pub && (fr - pub >= (uint32_t)kRescanEvery || fr == nsteps)) {
                 // steps 0 .. fr-1 are complete: everything owned by ids >= first id of step fr-1 is final
                 const int32_t sw = T.px_hi - T.px_lo + 1, sh = T.py_hi - T.py_lo + 1;
