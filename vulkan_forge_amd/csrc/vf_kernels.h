@@ -534,7 +534,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
     // (a triangle whose lanes have a line or two each gains nothing from the test -- a 4-pixel strip's triangles have four lines in
     //  all: their groups all count as open, and a wave without any other triangle skips the loop)
 #ifndef VF_GROUP_MIN
-#define VF_GROUP_MIN 2
+#define VF_GROUP_MIN 1
 #endif
     const bool test_groups = n_outer + 1 > VF_GROUP_MIN * nsub;
     gmask = test_groups ? 0u : (1u << ng) - 1u;
@@ -1535,7 +1535,7 @@ next_item:
 #define VF_CAND_PAIRS 1
 #endif
 #ifndef VF_CAND_PAIRS_MIN_ROWS
-#define VF_CAND_PAIRS_MIN_ROWS 64
+#define VF_CAND_PAIRS_MIN_ROWS 0
 #endif
         // (in the kernel instantiation WITHOUT line groups only -- the one a handle ends up with when its items are narrow strips of
         //  far-field tiles, hundreds of rows each: C4, a rank of eight 0.214 -> 0.199 ms; the other instantiation's wide items have a
