@@ -577,8 +577,9 @@ def main():
             "frame_ms": frame_ms,
             "shade_precision": "fast (hardware rcp/rsq/sin/cos/log/exp, within 1 LSB of the exact path; visibility identical)",
             # which of the raster stage's two line loops drew the timed frames (the handle times both on the settle frames and keeps the
-            # faster per view: vf_terrain_set_raster_groups) and what its probes measured for the main tile kernel alone
-            "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "tile_kernel_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
+            # faster per view: vf_terrain_set_raster_groups) and what its probes measured for a frame's work on the draw stream
+            # (k_clear + k_tile + the complete variant's launch), per variant
+            "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "draw_stream_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
             "roofline": roofline,
             "roofline_fragment": frag,
             "cpu_baseline": cpu,

@@ -714,6 +714,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const bool fresh = t->camera_moving || t->was_moving || (t->frames_since_reset >= 1 && t->frames_since_reset < vf_terrain::kPlanStates);
     const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");   // no tile times at all yet: a static estimate stands in (k_plan_estimate)
     t->frames_since_reset++;
+    const bool motion_starts = t->camera_moving && !t->was_moving;
     t->was_moving = t->camera_moving;
     const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
@@ -783,6 +784,52 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (t->last_stream && t->last_stream != s && t->rendered && (!overlap_frames || t->last_out == t->d_rgba || stats || write_vis || !t->last_out))
         VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
+    // line groups in the raster's line loop (vf_kernels.h, raster_fast): whole frames and shards of few ranks -- wide items, triangles
+    // with many lines -- gain from them (C4: one GPU -2 %, top-down camera -7 %); a rank of many mostly draws narrow strips, whose
+    // triangles have a handful of lines, and is better off with the leaner kernel (VF_GROUPS=0 / 1 overrides)
+    static const int groups_env = std::getenv("VF_GROUPS") ? std::atoi(std::getenv("VF_GROUPS")) : -1;
+    const int forced = groups_env >= 0 ? groups_env : t->groups_mode;
+    // the variant by default: groups for whole frames and shards of few ranks, none for a rank of many (mostly narrow strips)
+    const int guess = t->nranks < (uint32_t)VF_GROUPS_MAX_RANKS ? 1 : 0;
+    int pick = guess;
+    if (!VF_GROUPED) pick = 0;
+    else if (forced >= 0) pick = forced != 0;
+    else {
+        // probes that have completed (frames behind us: never a wait)
+        for (auto &g : t->gprobe)
+            if (g.pending && hipEventQuery(g.b) == hipSuccess) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && ms > 0.0f) {
+                    // the probe window's frames count alike; a later look weighs as much as all before it (the view may have drifted)
+                    const uint32_t n = ++t->g_n[g.variant];
+                    t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 4u ? n : 2u);
+                }
+                g.pending = false;
+            }
+        (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
+        // what was measured belongs to another layout, or to the view before the camera started to move (a camera that keeps moving
+        // keeps its choice -- an orbit's poses differ little in what suits them -- and is looked at again every kAgain frames)
+        if (t->frames_since_reset <= 1 || motion_starts) { t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }
+        // the plan settles for six frames on the default variant; then eight frames AABBAABB -- interleaved, so that what is left of the
+        // plan's settling, and the two plan states the frames alternate between, weigh on both alike; then the faster one, looked at
+        // again now and then
+        const uint32_t e = t->g_epoch_frames++;
+        constexpr uint32_t kSettle = 6, kProbe = 8, kAgain = 128;
+        if (e < kSettle) pick = guess;
+        else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) >> 1) & 1u);
+        else if (t->g_n[0] && t->g_n[1]) {
+            pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
+            if (e % kAgain == kAgain - 1) pick = !pick;           // (one frame of the other variant -- and the one before it of this -- keeps the times current)
+        }
+    }
+    t->groups_now = pick;
+    const bool groups = pick != 0;
+    // timed: the frames of the two probe windows, and now and then one frame of each variant (an event pair costs a marker packet or two)
+    const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
+    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 6u && e_now < 14u) || e_now % 128u >= 126u);
+    vf_terrain::GroupProbe *gp = nullptr;
+    if (probe) { gp = &t->gprobe[t->gprobe_head++ % 8]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
+    if (gp) VF_HIP_TRY(hipEventRecord(gp->a, s));          // (in front of k_clear: what is timed is the frame's whole work on the draw stream)
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
         hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats, seg_count);
@@ -795,57 +842,13 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
         const bool fast = fast_shading(t);
-        // line groups in the raster's line loop (vf_kernels.h, raster_fast): whole frames and shards of few ranks -- wide items, triangles
-        // with many lines -- gain from them (C4: one GPU -2 %, top-down camera -7 %); a rank of many mostly draws narrow strips, whose
-        // triangles have a handful of lines, and is better off with the leaner kernel (VF_GROUPS=0 / 1 overrides)
-        static const int groups_env = std::getenv("VF_GROUPS") ? std::atoi(std::getenv("VF_GROUPS")) : -1;
-        const int forced = groups_env >= 0 ? groups_env : t->groups_mode;
-        // the variant by default: groups for whole frames and shards of few ranks, none for a rank of many (mostly narrow strips)
-        const int guess = t->nranks < (uint32_t)VF_GROUPS_MAX_RANKS ? 1 : 0;
-        int pick = guess;
-        if (!VF_GROUPED) pick = 0;
-        else if (forced >= 0) pick = forced != 0;
-        else {
-            // probes that have completed (frames behind us: never a wait)
-            for (auto &g : t->gprobe)
-                if (g.pending && hipEventQuery(g.b) == hipSuccess) {
-                    float ms = 0.0f;
-                    if (hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && ms > 0.0f) {
-                        // the probe window's frames count alike; a later look weighs as much as all before it (the view may have drifted)
-                        const uint32_t n = ++t->g_n[g.variant];
-                        t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 4u ? n : 2u);
-                    }
-                    g.pending = false;
-                }
-            (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
-            if (fresh || t->frames_since_reset <= 1) { t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }   // what was measured belongs to another view / layout
-            // the plan settles for six frames on the default variant; then eight frames AABBAABB -- interleaved, so that what is left of the
-            // plan's settling, and the two plan states the frames alternate between, weigh on both alike; then the faster one, looked at
-            // again now and then
-            const uint32_t e = t->g_epoch_frames++;
-            constexpr uint32_t kSettle = 6, kProbe = 8, kAgain = 256;
-            if (e < kSettle) pick = guess;
-            else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) >> 1) & 1u);
-            else if (t->g_n[0] && t->g_n[1]) {
-                pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
-                if (e % kAgain == kAgain - 1) pick = !pick;           // (one frame of the other variant -- and the one before it of this -- keeps the times current)
-            }
-        }
-        t->groups_now = pick;
-        const bool groups = pick != 0;
-        // timed: the frames of the two probe windows, and now and then one frame of each variant (an event pair costs a marker packet or two)
-        const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
-        const bool probe = VF_GROUPED && forced < 0 && ((e_now >= 6u && e_now < 14u) || e_now % 256u >= 254u);
-        vf_terrain::GroupProbe *gp = nullptr;
-        if (probe) { gp = &t->gprobe[t->gprobe_head++ % 8]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
-        if (gp) VF_HIP_TRY(hipEventRecord(gp->a, s));
         // (the complete variant redraws the rare items that met a clipped primitive: always the plain loop)
 #define VF_TILE_LAUNCH(WV, FS)                                                                                         \
         do {                                                                                                           \
             if (groups) hipLaunchKernelGGL((k_tile<WV, false, FS, true>), per_cu, threads, 0, s, VF_TILE_ARGS);        \
             else hipLaunchKernelGGL((k_tile<WV, false, FS, false>), per_cu, threads, 0, s, VF_TILE_ARGS);              \
-            if (gp) { (void)hipEventRecord(gp->b, s); gp->variant = groups ? 1 : 0; gp->pending = true; gp = nullptr; } \
             hipLaunchKernelGGL((k_tile<WV, true, FS, false>), few, threads, 0, s, VF_TILE_ARGS);                       \
+            if (gp) { (void)hipEventRecord(gp->b, s); gp->variant = groups ? 1 : 0; gp->pending = true; gp = nullptr; } \
         } while (0)
         if (write_vis && fast) VF_TILE_LAUNCH(true, true);
         else if (write_vis) VF_TILE_LAUNCH(true, false);
