@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, the handle probes its two line loops (frames 6..13)
+SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, the handle probes its two line loops (frames 4..15)
 
 
 def parse():
@@ -577,9 +577,9 @@ def main():
             "frame_ms": frame_ms,
             "shade_precision": "fast (hardware rcp/rsq/sin/cos/log/exp, within 1 LSB of the exact path; visibility identical)",
             # which of the raster stage's two line loops drew the timed frames (the handle times both on the settle frames and keeps the
-            # faster per view: vf_terrain_set_raster_groups) and what its probes measured for a frame's work on the draw stream
-            # (k_clear + k_tile + the complete variant's launch), per variant
-            "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "draw_stream_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
+            # faster per view: vf_terrain_set_raster_groups) and what its probes measured: the frame period (end of one frame's work on the
+            # draw stream to the end of the next, both drawn by the same variant), per variant
+            "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "frame_period_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
             "roofline": roofline,
             "roofline_fragment": frag,
             "cpu_baseline": cpu,

@@ -129,12 +129,12 @@ int vf_terrain_set_shade_precision(vf_terrain *t, int precision);
 /* The raster stage's line loop exists twice (round 4): with and without a first pass that tests a triangle's lines in groups of four
  * against the final-pixel masks.  Which one is faster depends on the view and on how the frame is cut (wide items with many-line
  * triangles gain, a multi-GPU rank's narrow strips lose); the picture never differs.  mode -1 (default): the handle times both on
- * its own frames (HIP events around the frame's kernels on the draw stream, read back frames later, never a wait) and keeps the
- * faster one per view -- re-measured when the shard layout, the heights or (at the start of a motion) the camera change;
+ * its own frames (one HIP event at the end of a frame's work on the draw stream; the time between two consecutive frames of one
+ * variant -- the frame period -- read back frames later, never a wait) and keeps the faster one per view; re-measured when the shard
+ * layout, the heights or (at the start of a motion) the camera change;
  * 0 / 1: fixed.  No reference counterpart: the fixed-function raster behind draw_indexed, src/terrain/mod.rs:435. */
 int vf_terrain_set_raster_groups(vf_terrain *t, int mode);
-/* which variant drew the last frame (0 / 1) and, when measured, what a frame's work on the draw stream (k_clear + k_tile + the
- * complete variant's launch) took with each in this view (ms; 0 = not measured) */
+/* which variant drew the last frame (0 / 1) and, when measured, the frame period with each in this view (ms; 0 = not measured) */
 int vf_terrain_raster_groups(const vf_terrain *t, int *in_use, float ms[2]);
 
 /* Multi-GPU screen split (new; the reference is single-device).  Pixel row y belongs to this

@@ -532,7 +532,7 @@ def test_both_line_loops_of_the_raster_draw_the_same_frame(cabi, oracle, luts, c
             t.set_raster_groups(mode)
             if shard: t.set_tile_shard(shard[0], shard[1], 0)
             else: t.set_shard(0, 1, 64)
-            for _ in range(18 if mode < 0 else 4):                  # (-1: past the probe window)
+            for _ in range(20 if mode < 0 else 4):                  # (-1: past the probe window)
                 t.render()
             fast = t.read_tiles() if shard else t.read_rgba()
             if mode >= 0:

@@ -169,9 +169,11 @@ struct vf_terrain {
     // cut (C4: groups -7 % on the top-down camera at any rank count, -1.5 % on one GPU at the default camera, +5 % on a rank of eight,
     // whose items are narrow strips).  Never a difference in the picture.  groups_mode: -1 measure and choose, 0 / 1 fixed.
     int groups_mode = -1;
-    struct GroupProbe { hipEvent_t a = nullptr, b = nullptr; int variant = 0; bool pending = false; } gprobe[8];
-    uint32_t gprobe_head = 0;
-    float g_ms[2] = { 0.0f, 0.0f };      // tile-kernel time of each variant in this epoch (mean of the probes taken)
+    // A probe = an event at the end of a frame's work on the draw stream; a sample = the time between the ends of two consecutive
+    // frames drawn by the SAME variant: the frame period, the very thing to be minimised, whether frames overlap or wait for each other.
+    struct GroupProbe { hipEvent_t b = nullptr; int variant = 0; uint32_t seq = 0, epoch = 0; bool pending = false, valid = false; } gprobe[16];
+    uint32_t gprobe_head = 0, g_epoch_id = 0;
+    float g_ms[2] = { 0.0f, 0.0f };      // frame period with each variant in this epoch (mean of the samples taken)
     uint32_t g_n[2] = { 0u, 0u };
     uint32_t g_epoch_frames = 0;         // frames since the epoch began (shard change, height upload, camera jump)
     int groups_now = 1;                  // the variant of the frame rendered last
@@ -378,7 +380,7 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
         for (int k = 0; k < 5 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
-    for (auto &g : t->gprobe) { if (err == hipSuccess) err = hipEventCreate(&g.a); if (err == hipSuccess) err = hipEventCreate(&g.b); }
+    for (auto &g : t->gprobe) { if (err == hipSuccess) err = hipEventCreate(&g.b); }
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -416,7 +418,7 @@ void vf_terrain_destroy(vf_terrain *t)
     if (t->h_png) (void)hipHostFree(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
-    for (auto &g : t->gprobe) { if (g.a) (void)hipEventDestroy(g.a); if (g.b) (void)hipEventDestroy(g.b); }
+    for (auto &g : t->gprobe) { if (g.b) (void)hipEventDestroy(g.b); }
     delete t;
 }
 
@@ -430,7 +432,7 @@ int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44])
 
 static int set_height_common(vf_terrain *t, uint32_t tw, uint32_t th)
 {
-    t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0;     // other heights: which line loop is faster is measured again
+    t->g_epoch_frames = 0; t->g_epoch_id++; t->g_n[0] = t->g_n[1] = 0;     // other heights: which line loop is faster is measured again
     bool resized = tw != t->tw || th != t->th;
     t->tw = tw; t->th = th;
     if (resized) return refresh_tables(t, t->ctx->stream);
@@ -505,7 +507,7 @@ int vf_terrain_set_raster_groups(vf_terrain *t, int mode)
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (mode < -1 || mode > 1) return fail(VF_ERR_INVALID, "mode must be -1 (measure and choose), 0 or 1");
     t->groups_mode = mode;
-    t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f;
+    t->g_epoch_frames = 0; t->g_epoch_id++; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f;
     return VF_OK;
 }
 
@@ -795,41 +797,44 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (!VF_GROUPED) pick = 0;
     else if (forced >= 0) pick = forced != 0;
     else {
-        // probes that have completed (frames behind us: never a wait)
+        // probes that have completed (frames behind us: never a wait): a frame whose predecessor was probed too, and drawn by the same
+        // variant, yields a sample -- the time from that frame's end to its own
         for (auto &g : t->gprobe)
             if (g.pending && hipEventQuery(g.b) == hipSuccess) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && ms > 0.0f) {
-                    // the probe window's frames count alike; a later look weighs as much as all before it (the view may have drifted)
-                    const uint32_t n = ++t->g_n[g.variant];
-                    t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 4u ? n : 2u);
-                }
                 g.pending = false;
+                for (const auto &q : t->gprobe)
+                    if (q.valid && !q.pending && q.epoch == g.epoch && q.seq + 1u == g.seq && q.variant == g.variant) {
+                        float ms = 0.0f;
+                        if (hipEventElapsedTime(&ms, q.b, g.b) == hipSuccess && ms > 0.0f) {
+                            // the probe window's samples count alike; a later look weighs as much as all before it (the view may have drifted)
+                            const uint32_t n = ++t->g_n[g.variant];
+                            t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 4u ? n : 2u);
+                        }
+                    }
             }
         (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
         // what was measured belongs to another layout, or to the view before the camera started to move (a camera that keeps moving
         // keeps its choice -- an orbit's poses differ little in what suits them -- and is looked at again every kAgain frames)
-        if (t->frames_since_reset <= 1 || motion_starts) { t->g_epoch_frames = 0; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }
-        // the plan settles for six frames on the default variant; then eight frames AABBAABB -- interleaved, so that what is left of the
-        // plan's settling, and the two plan states the frames alternate between, weigh on both alike; then the faster one, looked at
-        // again now and then
+        if (t->frames_since_reset <= 1 || motion_starts) { t->g_epoch_frames = 0; t->g_epoch_id++; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }
+        // the plan settles for four frames on the default variant; then twelve frames AAABBBAAABBB -- interleaved, so that what is left
+        // of the plan's settling weighs on both alike, in runs of three, so that every run yields two periods between frames of one
+        // variant; then the faster one, looked at again now and then (four frames: AABB)
         const uint32_t e = t->g_epoch_frames++;
-        constexpr uint32_t kSettle = 6, kProbe = 8, kAgain = 128;
+        constexpr uint32_t kSettle = 4, kProbe = 12, kAgain = 128;
         if (e < kSettle) pick = guess;
-        else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) >> 1) & 1u);
+        else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) / 3u) & 1u);
         else if (t->g_n[0] && t->g_n[1]) {
             pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
-            if (e % kAgain == kAgain - 1) pick = !pick;           // (one frame of the other variant -- and the one before it of this -- keeps the times current)
+            if (e % kAgain >= kAgain - 2u) pick = !pick;          // (two frames of the other variant -- behind two timed ones of this -- keep the periods current)
         }
     }
     t->groups_now = pick;
     const bool groups = pick != 0;
-    // timed: the frames of the two probe windows, and now and then one frame of each variant (an event pair costs a marker packet or two)
+    // timed: the frames of the probe window (from the last settle frame on), and now and then two frames of each variant (one event each)
     const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
-    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 6u && e_now < 14u) || e_now % 128u >= 126u);
+    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 3u && e_now < 16u) || e_now % 128u >= 124u);
     vf_terrain::GroupProbe *gp = nullptr;
-    if (probe) { gp = &t->gprobe[t->gprobe_head++ % 8]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
-    if (gp) VF_HIP_TRY(hipEventRecord(gp->a, s));          // (in front of k_clear: what is timed is the frame's whole work on the draw stream)
+    if (probe) { gp = &t->gprobe[t->gprobe_head++ % 16]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
         hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats, seg_count);
@@ -848,7 +853,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
             if (groups) hipLaunchKernelGGL((k_tile<WV, false, FS, true>), per_cu, threads, 0, s, VF_TILE_ARGS);        \
             else hipLaunchKernelGGL((k_tile<WV, false, FS, false>), per_cu, threads, 0, s, VF_TILE_ARGS);              \
             hipLaunchKernelGGL((k_tile<WV, true, FS, false>), few, threads, 0, s, VF_TILE_ARGS);                       \
-            if (gp) { (void)hipEventRecord(gp->b, s); gp->variant = groups ? 1 : 0; gp->pending = true; gp = nullptr; } \
+            if (gp) { (void)hipEventRecord(gp->b, s); gp->variant = groups ? 1 : 0; gp->seq = e_now; gp->epoch = t->g_epoch_id; gp->pending = true; gp->valid = true; gp = nullptr; } \
         } while (0)
         if (write_vis && fast) VF_TILE_LAUNCH(true, true);
         else if (write_vis) VF_TILE_LAUNCH(true, false);
