@@ -2,7 +2,7 @@
 # tools/build_variant.sh NAME [-DFLAG=..]...   ->  build/variants/libvf_NAME.so  (kernel experiments; compare with tools/quick_variants.sh)
 name=$1; shift
 mkdir -p build/variants
-# (the flags of __graft_entry__.build(); VF_NO_TUNING=1 leaves the three -mllvm register-allocation switches out)
-tuning="-mllvm -disable-machine-licm -mllvm -greedy-regclass-priority-trumps-globalness -mllvm -amdgpu-schedule-relaxed-occupancy"
+# (the flags of __graft_entry__.build(); VF_NO_TUNING=1 leaves the -mllvm code-generation switches out)
+tuning="-mllvm -disable-machine-licm -mllvm -greedy-regclass-priority-trumps-globalness -mllvm -amdgpu-schedule-relaxed-occupancy -mllvm -simplifycfg-sink-common=false -mllvm -simplifycfg-hoist-common=false"
 [ -n "$VF_NO_TUNING" ] && tuning=""
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $tuning "$@" vulkan_forge_amd/csrc/vf_hip.hip -o build/variants/libvf_$name.so

@@ -1,5 +1,5 @@
 // vf_hip.hip -- C-ABI (include/vf_hip.h) over the gfx950 kernels in vf_kernels.h.
-// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC + three -mllvm register-allocation switches (HIPCC_TUNING)
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC + the -mllvm code-generation switches of HIPCC_TUNING
 #include "../../include/vf_hip.h"
 #include "vf_kernels.h"
 
