@@ -62,7 +62,7 @@ for n in ("fetch_default", "write_default", "frag_fetch_default", "frag_write_de
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
 for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log", "rank0_stitch.log", "cold.log", "fragment.log", "parity_soak.log"):
     copy(n, n)
-for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.log", "stripes.log"):      # round 4
+for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.log", "stripes.log", "hw_shift64_probe.log"):      # round 4
     if os.path.exists(os.path.join(G, n)):
         copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))

@@ -2245,6 +2245,7 @@ __global__ __launch_bounds__(256) void k_triangle(uint32_t W, uint32_t H, const 
     __shared__ float s_thr[256];
     s_thr[threadIdx.x] = thresh[threadIdx.x];
     __syncthreads();
+    VF_RESERVE_VGPR(16);   // 17 registers, not 16: see vf_device.h (the int64 -> float conversions below shift by a register amount)
     size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (size_t)W * H) return;
     int32_t py = (int32_t)(p / W), px = (int32_t)(p - (size_t)py * W);
