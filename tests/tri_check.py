@@ -1,5 +1,5 @@
 """Triangle smoke path of a given library against the oracle at several sizes, with the shape of any difference.
-usage (GPU box): python tools/tri_check.py path/to/libvf.so"""
+usage (GPU box): python tests/tri_check.py path/to/libvf.so"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 import numpy as np

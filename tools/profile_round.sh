@@ -48,6 +48,6 @@ echo "== line loops"; timeout -k 10 300 python tools/exp_groups_auto.py > "$out/
 echo "== stripe widths"; (timeout -k 10 300 python tools/exp_ranks.py default 1:0 2:0:0 2:0:1 2:0:2 2:0:3 4:0:0 4:0:1 4:0:2 8:0:0 8:0:1 8:0:2; timeout -k 10 300 python tools/exp_ranks.py fill 1:0 2:0:0 2:0:2 4:0:0 4:0:1 8:0:0 8:0:1) > "$out/stripes.log" 2>&1; grep -c period "$out/stripes.log"
 # round 4: the hardware finding behind tools/isa_lint.py -- 64-bit shifts by the last allocated VGPR -- reproduced with its controls
 echo "== hardware probes"; mkdir -p build; (hipcc --offload-arch=gfx950 -O2 tools/probes/shift64_top.hip -o build/shift64_top && hipcc --offload-arch=gfx950 -O2 tools/probes/mad64_overlap.hip -o build/mad64_overlap && hipcc --offload-arch=gfx950 -O2 tools/probes/vgpr_top.hip -o build/vgpr_top) > "$out/hw_probe_build.log" 2>&1; rm -f ./*.hipfb
-(echo "# tools/probes/shift64_top.hip"; timeout -k 10 60 ./build/shift64_top; echo; echo "# tools/probes/vgpr_top.hip (a value parked in the last register survives: the register is intact, the shift's READ fails)"; timeout -k 10 60 ./build/vgpr_top | grep -v "end 3 waves early"; echo; echo "# tools/probes/mad64_overlap.hip (overlapping operands of v_mad_u64_u32: all right)"; timeout -k 10 60 ./build/mad64_overlap; echo; echo "# tools/isa_lint.py on the library under test"; python tools/isa_lint.py; echo; echo "# triangle path of the library under test"; timeout -k 10 100 python tools/tri_check.py vulkan_forge_amd/libvf_hip.so) > "$out/hw_shift64_probe.log" 2>&1; grep -c "lanes wrong" "$out/hw_shift64_probe.log"
+(echo "# tools/probes/shift64_top.hip"; timeout -k 10 60 ./build/shift64_top; echo; echo "# tools/probes/vgpr_top.hip (a value parked in the last register survives: the register is intact, the shift's READ fails)"; timeout -k 10 60 ./build/vgpr_top | grep -v "end 3 waves early"; echo; echo "# tools/probes/mad64_overlap.hip (overlapping operands of v_mad_u64_u32: all right)"; timeout -k 10 60 ./build/mad64_overlap; echo; echo "# tools/isa_lint.py on the library under test"; python tools/isa_lint.py; echo; echo "# triangle path of the library under test"; timeout -k 10 100 python tests/tri_check.py vulkan_forge_amd/libvf_hip.so) > "$out/hw_shift64_probe.log" 2>&1; grep -c "lanes wrong" "$out/hw_shift64_probe.log"
 echo "== soak"; timeout -k 10 500 python tests/soak_parity.py $((500000 + RANDOM)) 100000 400 > "$out/parity_soak.log" 2>&1; tail -1 "$out/parity_soak.log"
 echo "== done"
