@@ -1697,6 +1697,19 @@ next_item:
 #endif
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
+#if VF_WAVE_PRIO
+            // WAVE PRIORITY (round 4).  What every wave of the tile culls against -- blocks, triangles, lines, pixels -- is the set of FINAL
+            // pixels, and that set grows when the oldest unfinished step completes and its completer has rescanned the tile.  So the
+            // wave that holds a block of that step goes first on its SIMD (s_setprio 2), the step behind it next (1), everything
+            // younger last (0), and the rescan itself above all of them (3, below): the masks come out earlier and everybody else does
+            // less.  Scheduling only -- the same pixels.  C4: one GPU -2 %, top-down camera -5.7 %, a rank of eight at that camera -4 %.
+            // In the instantiation for wide items only (GROUPS): the narrow strips of a many-rank shard and the C5 orbit, which the
+            // other instantiation draws, gain nothing (a rank of eight at the default camera +1 %, C5 +-0); VF_WAVE_PRIO=2 has both.
+            if (VF_WAVE_PRIO == 2 || GROUPS) {
+                const uint32_t fr_now = lds_peek(&s_frontier);
+                if (stepidx <= fr_now) __builtin_amdgcn_s_setprio(2); else if (stepidx == fr_now + 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             // One round trip for everything the block needs from HBM: its record (pixel box, alive masks) and its 81 snapped
             // vertices are requested together, before the box decides whether the block is still worth drawing -- a dependent
             // second trip costs a wave more than the vertices of the blocks that turn out culled.
@@ -1874,6 +1887,9 @@ next_item:
             if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
             got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             if (!got) { VF_PH(5) continue; }                           // somebody else is publishing; masks may lag, never lie
+#if VF_WAVE_PRIO
+            if (VF_WAVE_PRIO == 2 || GROUPS) __builtin_amdgcn_s_setprio(3);   // the publisher of new final-pixel masks: before everything else (above)
+#endif
             uint32_t fr = lds_peek(&s_frontier);
             while (fr < nsteps && lds_peek(&s_pending[fr]) == 0u) ++fr;
             const uint32_t pub = lds_peek(&s_published);
@@ -1885,9 +1901,15 @@ next_item:
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) { s_done = 1u; atomicOr(&s_next, 0x40000000u); } }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
+#if VF_WAVE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             VF_PH(5)
         }
         VF_PH(1)
+#if VF_WAVE_PRIO
+        __builtin_amdgcn_s_setprio(0);                                 // (the last block's priority ends with the block loop)
+#endif
         if (lane == 0 && my_blocks) atomicAdd(&s_blocks, my_blocks);
         __syncthreads();
 #ifdef VF_DBG_LOOPTIME
