@@ -1,6 +1,6 @@
 """When does each work item of a frame start and end?  (library built with -DVF_DBG_ITEMSTART: the item statistics' block column holds the
 start tick.)  Prints the frame's schedule: items in flight over time, when the last item of each weight class starts, the idle share.
-usage: exp_gantt.py [camera] [rank n]"""
+usage: exp_gantt.py [camera] [rank n [stripe_log2]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,7 @@ cam = sys.argv[1] if len(sys.argv) > 1 else "default"
 shard = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None
 h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 t = cabi.Terrain(W, H, G, vf.colormap_rgba8("viridis")); t.set_height(h); t.set_uniforms(b.camera_uniforms(cam, W, H))
-if shard: t.set_tile_shard(shard[0], shard[1], 0)
+if shard: t.set_tile_shard(shard[0], shard[1], (int(sys.argv[4]) << 16) if len(sys.argv) > 4 else 0)
 for _ in range(30): t.render()
 for rep in range(2):
     t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
