@@ -38,9 +38,6 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #ifndef VF_WAVE_PRIO
 #define VF_WAVE_PRIO 1            // the tile kernel's waves take SIMD priorities by how close their block is to the finality frontier (vf_kernels.h): 0 off, 1 wide-item instantiation, 2 both
 #endif
-#ifndef VF_FRAG_PATCH
-#define VF_FRAG_PATCH 0
-#endif
 #ifndef VF_RESCAN_EVERY
 #define VF_RESCAN_EVERY 1
 #endif

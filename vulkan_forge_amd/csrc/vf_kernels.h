@@ -2011,16 +2011,7 @@ next_item:
     if (shade) {
     if (item_w > 32 || (item_w & (item_w - 1)) != 0) {     // whole tiles, and tiles the target's right edge cuts
         for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
-#if VF_FRAG_PATCH
-            // a wave shades an 8 x 8 pixel patch, not a 64-pixel row: neighbours in two dimensions share vertex records (a visible
-            // primitive's three records sit in two 144-byte rows of its block), neighbours along a row share few on a noise terrain --
-            // what made the stage as a launch of its own (k_resolve4) twice as fast.  The eight waves of a patch row complete whole
-            // 256-byte row segments between them.
-            const int32_t patch = k >> 6, l = k & 63;
-            const int32_t lx = ((patch & 7) << 3) | (l & 7), ly = ((patch >> 3) << 3) | (l >> 3);
-#else
             const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
-#endif
             const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
             if (px > T.px_hi || py > T.py_hi) continue;
             const uint32_t id = s_vis[vis_index(lx, ly)];
