@@ -127,7 +127,8 @@ struct vf_terrain {
         float4 *cap_seg = nullptr;       // per block: capsule axis (screen space)
         float *cap_rad = nullptr;        // per block: capsule radius
         uint32_t *rc = nullptr;          // per (tile column, block row): [lo | hi) block-column range, 2 * nb * ntx words
-        uint2 *work = nullptr;           // busy tiles of the frame: (item, weight), heaviest first
+        uint2 *work = nullptr;           // busy tiles of the frame: (item, weight) as k_plan lists them
+        uint2 *work_sorted = nullptr;    // ... heaviest first (k_plan_sort; the second half of the same allocation): what the tile kernel pulls from
         uint32_t *work_count = nullptr;  // [0] work items, [1] split budget used, [2] queue head, [3] items handed to the complete tile kernel
         uint32_t *redo = nullptr;        // those items (indices into work)
         uint32_t *background = nullptr;  // per local tile: bit 0 = no block row reaches it; bits 8.. = log2 of the strips it is cut into
@@ -351,7 +352,8 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
         A((void **)&S.cap_seg, t->nblocks * sizeof(float4));
         A((void **)&S.cap_rad, t->nblocks * sizeof(float));
         A((void **)&S.rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
-        A((void **)&S.work, (all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting
+        A((void **)&S.work, 2 * (size_t)(all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting: as planned, and (second half) ordered
+        S.work_sorted = S.work + (all_tiles + kSplitBudget + 16);
         A((void **)&S.feedback, (all_tiles * 65 + 1) * sizeof(uint32_t));
         A((void **)&S.work_count, 4 * sizeof(uint32_t));
         A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
@@ -769,7 +771,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.flags_new, S.work, S.work_count,
                            F.feedback, quantum, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
-        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(1024), 0, side, S.work, S.work_count, S.feedback, t->ntx * t->nty,
+        hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(256), 0, side, S.work, S.work_sorted, S.work_count, S.feedback, t->ntx * t->nty,
                            S.flags_new, S.background, ntiles);
     }
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
@@ -844,7 +846,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         const dim3 per_cu(std::min<uint32_t>((uint32_t)std::max(1, t->ctx->prop.multiProcessorCount) * (1024u / (uint32_t)kTileThreads), ntiles + kSplitBudget)),
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
         const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
-#define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work, S.work_count, \
+#define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work_sorted, S.work_count, \
                      rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
         const bool fast = fast_shading(t);
         // (the complete variant redraws the rare items that met a clipped primitive: always the plain loop)

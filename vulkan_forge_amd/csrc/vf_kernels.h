@@ -1303,51 +1303,52 @@ __global__ __launch_bounds__(256) void k_clear(FrameParams P, const uint32_t *__
 // read them).  The order only steers scheduling -- heaviest first, so that the long items start first and the launch's tail stays
 // short -- and needs no more than that: a counting sort on a 10-bit logarithmic key (the weight's exponent and five mantissa bits:
 // 2 % steps), four barriers per run of 4096 items instead of the 66 passes of the bitonic sort this replaces (round 4: 25 us alone
-// and 110 us under the tile kernel -> 6 / 20 us; it is on the critical path of a handle's first frames and of a moving camera, whose
-// plan waits for the previous frame).  Items of one key keep no particular order.  Lists longer than 4096 are ordered in
-// independent 4096-item runs, which is all the scheduler needs.
-__global__ __launch_bounds__(1024) void k_plan_sort(uint2 *__restrict__ work, const uint32_t *__restrict__ work_count,
-                                                    uint32_t *__restrict__ last_blocks, uint32_t ntiles,
-                                                    const uint32_t *__restrict__ flags_new, uint32_t *__restrict__ background, uint32_t nlocal)
+// -> 5 us; it is on the critical path of a handle's first frames and of a moving camera, whose plan waits for the previous frame).
+// Out of place (work -> sorted), four waves, nothing held in registers across a barrier: the kernel has to find a place BESIDE a
+// resident tile-kernel workgroup and the set-up pass's workgroups that come and go -- as sixteen waves that need four free slots on
+// every SIMD of one CU at the same moment it waited for most of the frame to be launched at all (570 us "long" in the trace, 5 us
+// alone).  Items of one key keep no particular order.  Lists longer than
+// 4096 are ordered in independent 4096-item runs, which is all the scheduler needs.
+__global__ __launch_bounds__(256) void k_plan_sort(const uint2 *__restrict__ work, uint2 *__restrict__ sorted, const uint32_t *__restrict__ work_count,
+                                                   uint32_t *__restrict__ last_blocks, uint32_t ntiles,
+                                                   const uint32_t *__restrict__ flags_new, uint32_t *__restrict__ background, uint32_t nlocal)
 {
-    constexpr uint32_t kKeys = 1024;
+    constexpr uint32_t kKeys = 1024, kT = 256;             // four waves: one per SIMD finds a place at once beside whatever is resident
     __shared__ uint32_t s_hist[kKeys];                     // items per key, then the key's first position
-    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_kr[4096];                        // per item of the run: key | rank within the key << 10
+    __shared__ uint32_t s_wsum[kT / 64];
     const uint32_t n = *work_count, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t k = tid; k < ntiles; k += 1024) last_blocks[k] = 0u;       // this frame's tile kernel adds its times
-    for (uint32_t k = tid; k < nlocal; k += 1024) background[k] = flags_new[k];   // the plan is done reading the old words
+    for (uint32_t k = tid; k < ntiles; k += kT) last_blocks[k] = 0u;         // this frame's tile kernel adds its times
+    for (uint32_t k = tid; k < nlocal; k += kT) background[k] = flags_new[k];     // the plan is done reading the old words
     for (uint32_t base = 0; base < n; base += 4096) {
         const uint32_t m = min(4096u, n - base);
-        s_hist[tid] = 0u;
+        for (uint32_t k = tid; k < kKeys; k += kT) s_hist[k] = 0u;
         __syncthreads();
-        uint2 it[4];
-        uint32_t key[4], rank[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t k = tid + 1024u * (uint32_t)q;
-            key[q] = 0u; rank[q] = 0u; it[q] = make_uint2(0u, 0u);
-            if (k < m) {
-                it[q] = work[base + k];
-                // heaviest first: key 0 = the largest weights.  (float)w >> 18 = exponent and five mantissa bits; w >= 1
-                const uint32_t f = (__float_as_uint((float)max(it[q].y, 1u)) >> 18) - (127u << 5);
-                key[q] = (kKeys - 1u) - min(f, kKeys - 1u);
-                rank[q] = atomicAdd(&s_hist[key[q]], 1u);
-            }
+#pragma unroll 1
+        for (uint32_t k = tid; k < m; k += kT) {
+            // heaviest first: key 0 = the largest weights.  (float)w >> 18 = exponent and five mantissa bits; w >= 1
+            const uint32_t f = (__float_as_uint((float)max(work[base + k].y, 1u)) >> 18) - (127u << 5);
+            const uint32_t key = (kKeys - 1u) - min(f, kKeys - 1u);
+            s_kr[k] = key | (atomicAdd(&s_hist[key], 1u) << 10);
         }
         __syncthreads();
-        // exclusive prefix sum over the 1024 keys: one key per thread, DPP scan per wave, the sixteen wave totals by every thread
-        const uint32_t mine = s_hist[tid];
+        // exclusive prefix sum over the 1024 keys: four keys per thread, DPP scan per wave, the four wave totals by every thread
+        const uint32_t a0 = s_hist[4u * tid], a1 = s_hist[4u * tid + 1u], a2 = s_hist[4u * tid + 2u], a3 = s_hist[4u * tid + 3u];
+        const uint32_t mine = a0 + a1 + a2 + a3;
         const uint32_t inc = wave_scan_add(mine);
         if (lane == 63u) s_wsum[wave] = inc;
         __syncthreads();
         uint32_t before = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 16u; ++w) before += w < wave ? s_wsum[w] : 0u;
-        s_hist[tid] = before + inc - mine;
+        for (uint32_t w = 0; w < kT / 64; ++w) before += w < wave ? s_wsum[w] : 0u;
+        const uint32_t first = before + inc - mine;
+        s_hist[4u * tid] = first; s_hist[4u * tid + 1u] = first + a0; s_hist[4u * tid + 2u] = first + a0 + a1; s_hist[4u * tid + 3u] = first + a0 + a1 + a2;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (tid + 1024u * (uint32_t)q < m) work[base + s_hist[key[q]] + rank[q]] = it[q];   // (every item of the run is in a register by now)
+#pragma unroll 1
+        for (uint32_t k = tid; k < m; k += kT) {
+            const uint32_t kr = s_kr[k];
+            sorted[base + s_hist[kr & (kKeys - 1u)] + (kr >> 10)] = work[base + k];
+        }
         __syncthreads();
     }
 }
