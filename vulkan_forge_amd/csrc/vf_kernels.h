@@ -32,7 +32,7 @@
 // block row r: after a block row has been rasterised, covered pixels are final.
 //
 // Build-time switches (defaults are the measured optimum at C4; DESIGN.md section 7 has the sweeps): VF_TILE_MIN_WAVES (vf_device.h: the
-// tile kernel's register cap), VF_SPLIT_QUANTUM_X4, VF_RESCAN_EVERY, VF_CLS_LINES, VF_ROWS_AT_ONCE, VF_MAX_STEPS; VF_SLICES=1 compiles
+// tile kernel's register cap), VF_SPLIT_QUANTUM_X4, VF_RESCAN_EVERY, VF_WAVE_PRIO, VF_CLS_LINES, VF_ROWS_AT_ONCE, VF_MAX_STEPS; VF_SLICES=1 compiles
 // the depth slices in; VF_PHASE_PROF the per-phase cycle counters; VF_DBG_* single-purpose experiment hooks of tools/exp_*.py.
 #pragma once
 #include "vf_device.h"
