@@ -144,15 +144,22 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
 int vf_terrain_local_rows(const vf_terrain *t, uint32_t *rows);
 
 /* Multi-GPU screen split by interleaved 64 x 64 tiles ("screen-tile split", BASELINE.json configs[3]; new, the reference
- * is single-device): tile (tx, ty) belongs to rank (tx + skew * ty) % nranks, so the heavy tiles of a frame -- they
- * cluster along the terrain's silhouette -- spread over all ranks.  A rank stores its tiles densely, row-major by
- * (ty, tx), each as 64 x 64 RGBA8 words (edge tiles keep the full slot): local tile k starts at byte k * 16384.
- * vf_tile_layout lists a rank's tiles (tx | ty << 16; pure host arithmetic, no device needed; tiles may be NULL to
- * count).  A tile-sharded handle is read with vf_terrain_read_tiles; rows come back after vf_stitch_tiles_device. */
-int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t skew);
+ * is single-device).  The `layout` argument of vf_terrain_set_tile_shard, vf_tile_layout and vf_stitch_tiles_device is ONE WORD,
+ * VF_TILE_LAYOUT(skew, stripe_log2) = skew | stripe_log2 << 16:
+ *     tile (tx, ty) belongs to rank ((tx >> stripe_log2) + skew * ty) % nranks
+ * -- column stripes 2^stripe_log2 tiles wide dealt round-robin to the ranks, each tile row shifted by `skew` stripes.  A plain
+ * number < 65536 is therefore a skew with single-tile stripes (the meaning the argument had before round 4).  skew 0 = column
+ * stripes (what vf_dist_exchange_bands needs, and bench.py's default with a period of eight tile columns: stripe_log2 2 / 1 / 0
+ * for 2 / 4 / 8 ranks).  skew < 65536 and stripe_log2 <= 15; a word with any higher bit set is refused (VF_ERR_INVALID).
+ * A rank stores its tiles densely, row-major by (ty, tx), each as 64 x 64 RGBA8 words (edge tiles keep the full slot): local
+ * tile k starts at byte k * 16384.  vf_tile_layout lists a rank's tiles (tx | ty << 16; pure host arithmetic, no device needed;
+ * tiles may be NULL to count).  A tile-sharded handle is read with vf_terrain_read_tiles; rows come back after
+ * vf_stitch_tiles_device. */
+#define VF_TILE_LAYOUT(skew, stripe_log2) ((uint32_t)(skew) | ((uint32_t)(stripe_log2) << 16))
+int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t layout);
 int vf_terrain_local_tiles(const vf_terrain *t, uint32_t *tiles);
 int vf_terrain_read_tiles(vf_terrain *t, uint8_t *dst, uint32_t first, uint32_t count);
-int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, uint32_t skew, uint32_t *tiles,
+int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, uint32_t layout, uint32_t *tiles,
                    uint32_t capacity, uint32_t *count);
 
 /* Render into a caller-provided device buffer of local_rows*W*4 bytes (tile shards: local_tiles*16384 bytes);
@@ -169,11 +176,31 @@ int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba);
  * is ordered and split follows the times measured on this handle's earlier frames -- that steers speed only, never a pixel.
  */
 int vf_terrain_render(vf_terrain *t, void *stream);
+/* BASELINE.json configs[4] ("batch of 64 camera look-ats over one terrain"): n render passes with n uniform blocks over the handle's
+ * terrain, queued back to back on `stream` -- the loop Scene.set_camera_look_at + render_png runs per pose (src/scene/mod.rs:208-224,
+ * :278-335) without the per-pose FFI round trips and read-backs.  uniforms: n x 44 floats (vf_terrain_set_uniforms layout);
+ * dev_rgba: n device buffers, frame k goes to dev_rgba[k] (NULL: every frame into the current output buffer, the last one stays).
+ * Every pose is planned from the tile times of the pose before last, looked up through the camera motion between the two (the
+ * homography of the ground plane): no pose waits for its predecessor's times, the plan and the set-up pass of pose k + 1 run under
+ * pose k's tile kernel.  Afterwards the handle's uniforms are the last pose's and its output buffer is dev_rgba[n - 1].
+ * Multi-GPU (pose-parallel replicas, no collective): rank r passes the poses k = r mod N. */
+int vf_terrain_render_batch(vf_terrain *t, const float *uniforms, uint32_t n, void *const *dev_rgba, void *stream);
+/* The same batch with every frame read back (the per-pose copy_texture_to_buffer + map of src/terrain/mod.rs:439-485): pose k is drawn
+ * into one of three device frames owned by the handle and copied to host_rgba[k] (H*W*4 bytes each; page-locked destinations --
+ * vf_host_alloc -- travel by DMA while the next poses are drawn).  Returns when every frame has arrived.  Whole-frame handles only.
+ * The handle's own output buffer is left untouched (and "nothing rendered yet" holds for it afterwards). */
+int vf_terrain_render_batch_host(vf_terrain *t, const float *uniforms, uint32_t n, uint8_t *const *host_rgba);
 int vf_terrain_sync(vf_terrain *t);
 
 /* copy_texture_to_buffer + map + un-pad (src/terrain/mod.rs:439-485): local rows [y0, y0+rows)
  * into dst (rows*W*4 bytes).  Synchronises the last render. */
 int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows);
+/* Page-locked host memory for read-back destinations (new; the reference maps a fresh staging buffer per call,
+ * src/terrain/mod.rs:446-451).  vf_terrain_read_rgba into such a buffer is ONE DMA transfer (C4: 64 MiB in 1.2 ms); into ordinary
+ * pageable memory it goes through the handle's ring of pinned chunks and a copy by host threads, and a frame-sized fresh
+ * destination is page-fault bound (2-5 ms).  Any hipHostMalloc / hipHostRegister memory of the caller's is recognised as well. */
+int vf_host_alloc(size_t bytes, void **host);
+void vf_host_free(void *host);
 /* Read-back for render_png (src/terrain/mod.rs:439-490): the last frame as PNG scanlines -- per row one filter-type byte
  * (row-adaptive: the filter with the smallest sum of absolute residuals, chosen on the GPU) followed by W*4 filtered
  * bytes -- in pinned host memory owned by the handle (allocated once, not per call as the reference's read-back buffer
@@ -247,9 +274,10 @@ int vf_dem_read_patch(vf_dem *d, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
  * possible).  All pointers are device pointers. */
 int vf_stitch_bands_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width,
                            uint32_t height, uint32_t nranks, uint32_t band_h, void *stream);
-/* Same for tile shards: gather buffer [nranks][stride_tiles][64][64][4] (stride_tiles >= the largest shard) -> (H,W,4). */
+/* Same for tile shards: gather buffer [nranks][stride_tiles][64][64][4] (stride_tiles >= the largest shard) -> (H,W,4);
+ * `layout` = the VF_TILE_LAYOUT word the shards were made with. */
 int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_image, uint32_t width, uint32_t height,
-                           uint32_t nranks, uint32_t skew, uint32_t stride_tiles, void *stream);
+                           uint32_t nranks, uint32_t layout, uint32_t stride_tiles, void *stream);
 
 /* ---- multi-GPU exchange over RCCL (new: the reference creates one device per object,
  * src/terrain/mod.rs:277-294, and has no exchange) -------------------------------------------------------------
@@ -259,9 +287,9 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
  *
  *   rank 0:  vf_dist_unique_id(id)            -> hand the 128 bytes to every rank (any host channel)
  *   all:     vf_dist_comm_init(ctx, id, rank, nranks, &comm)
- *   frame:   vf_terrain_set_tile_shard(t, rank, nranks, skew); vf_terrain_set_output_device(t, slab); vf_terrain_render(t, s);
+ *   frame:   vf_terrain_set_tile_shard(t, rank, nranks, layout); vf_terrain_set_output_device(t, slab); vf_terrain_render(t, s);
  *            vf_dist_gather_tiles(t, comm, 0, gathered, stride_tiles, s);      (all ranks; `gathered` used on the root)
- *            root: vf_stitch_tiles_device(ctx, gathered, image, W, H, nranks, skew, stride_tiles, s);
+ *            root: vf_stitch_tiles_device(ctx, gathered, image, W, H, nranks, layout, stride_tiles, s);
  *   or, with column stripes (skew 0) and a tile grid that divides by nranks -- the default of bench.py:
  *            vf_dist_exchange_bands(t, comm, 0, image, s);                     (all ranks; `image` used on the root; no root stitch)
  */

@@ -260,3 +260,28 @@ def test_large_readback_goes_through_the_pinned_ring_unchanged(luts, monkeypatch
     part = np.full((1500, W, 4), 7, np.uint8)
     t._check(t.lib.vf_terrain_read_rgba(t.t, part.ctypes.data, 1001, 1500))
     assert np.array_equal(part, want[1001:2501])
+
+
+def test_frame_sized_render_rgba_arrays_live_in_the_pinned_pool(oracle, luts, monkeypatch):
+    """Round 5: frame-sized render_rgba results are NumPy arrays over page-locked buffers of a pool (one DMA, no host copy); every call
+    returns its own array, a dead array's buffer is reused, and the pageable path (VF_RGBA_PAGEABLE) gives the same bytes."""
+    import gc
+    W, H, G = 1920, 1080, 256
+    s = vf.TerrainSpike(W, H, grid=G, colormap="viridis")
+    a = s.render_rgba()
+    b = s.render_rgba()
+    assert a.shape == (H, W, 4) and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"] and not a.flags["OWNDATA"]
+    assert a.ctypes.data != b.ctypes.data and np.array_equal(a, b)
+    ref, _ = oracle.render_terrain(oracle.default_uniforms(0, W, H), W, H, G, oracle.SPIKE_DUMMY_HEIGHT, luts["viridis"], nthreads=min(16, oracle.max_threads()), want_vis=False)
+    assert np.abs(a.astype(int) - ref.astype(int)).max() <= 1
+    keep = a.copy()
+    where = a.ctypes.data
+    a[:] = 0                                                     # the caller owns what it got
+    assert np.array_equal(b, keep)
+    del a
+    gc.collect()
+    c = s.render_rgba()                                          # the dead array's buffer comes back from the pool
+    assert c.ctypes.data == where and np.array_equal(c, keep)
+    monkeypatch.setenv("VF_RGBA_PAGEABLE", "1")
+    d = s.render_rgba()
+    assert d.flags["OWNDATA"] and np.array_equal(d, keep)

@@ -3,6 +3,6 @@
 name=$1; shift
 mkdir -p build/variants
 # (the flags of __graft_entry__.build(); VF_NO_TUNING=1 leaves the -mllvm code-generation switches out)
-tuning="-mllvm -disable-machine-licm -mllvm -greedy-regclass-priority-trumps-globalness -mllvm -amdgpu-schedule-relaxed-occupancy -mllvm -simplifycfg-sink-common=false -mllvm -simplifycfg-hoist-common=false -mllvm -disable-lsr -mllvm -phi-node-folding-threshold=4 -fno-slp-vectorize"
+tuning=$(python3 -c "import __graft_entry__ as g; print(' '.join(g.HIPCC_TUNING))")      # one list: the build's
 [ -n "$VF_NO_TUNING" ] && tuning=""
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $tuning "$@" vulkan_forge_amd/csrc/vf_hip.hip -o build/variants/libvf_$name.so && python tools/isa_lint.py build/variants/libvf_$name.so | grep -v ' 0 with the amount' ; true

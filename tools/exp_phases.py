@@ -15,7 +15,7 @@ for cam in ("default", "fill"):
     t.set_uniforms(b.camera_uniforms(cam, W, H))
     for _ in range(24): t.render()
     t.enable_timing(True); t.render(); tm = t.timings(); ph = t.phase_cycles().astype(float); it = t.item_stats(); t.enable_timing(False)
-    vsub = ph[30:32]; wv = ph[24:30]; sub = ph[16:24]; cnt = ph[8:16]; ph = ph[:8]; ph[0] += sub.sum(); ph[2] += vsub.sum()
+    vsub2 = ph[32:34]; vsub = ph[30:32]; wv = ph[24:30]; sub = ph[16:24]; cnt = ph[8:16]; ph = ph[:8]; ph[0] += sub.sum(); ph[2] += vsub.sum() + vsub2.sum()
     tot = ph.sum()
     live = max(cnt[7], 1)
     print(f"{cam}: tile_ms={tm['tile_ms']:.3f} pairs={tm['blocks_rasterised']} wave-cycles total={tot:.3e} (= {tot/16/2.4e6:.1f} ms of workgroup time at 2.4 GHz)")
@@ -25,7 +25,7 @@ for cam in ("default", "fill"):
     print(f"   line loop ({'with line groups: group-test trips' if use else 'plain: line trips'}={wv[0]/live:.2f}), wave-level executions per pair: lines reaching stage 1={wv[1]/live:.2f}  stage 2={wv[2]/live:.2f}  paint steps={wv[3]/live:.2f};  classification: triangles reaching the occlusion loop={wv[5]/live:.1f}, its wave-level iterations={wv[4]/live:.2f}")
     for n, c in zip(["row list", "candidate tests", "wait for slowest wave", "scan + list fill", "hand-over + pull", "item record + tile state", "row mask", "-"], sub):
         print(f"      set-up: {n:22s} {100*c/tot:6.2f} %")
-    print(f"      vertex: record wait {100*vsub[0]/tot:.2f} %  (one empty time stamp: {100*vsub[1]/tot:.2f} % = {vsub[1]/live:.0f} cycles per pair; every phase above holds one per boundary)  staging + alive-list compaction {100*(ph[2]-vsub.sum())/tot:.2f} %")
+    print(f"      vertex: record wait {100*vsub[0]/tot:.2f} %  (one empty time stamp: {100*vsub[1]/tot:.2f} % = {vsub[1]/live:.0f} cycles per pair; every phase above holds one per boundary)  wait for the vertex records {100*vsub2[0]/tot:.2f} % = {vsub2[0]/live:.0f} cycles per pair  LDS staging {100*vsub2[1]/tot:.2f} %  alive-list compaction {100*(ph[2]-vsub.sum()-vsub2.sum())/tot:.2f} %")
     print(f"   shader clock during the items: {tot / 16 / (it[:, 3].astype(float).sum() * 1e-8) / 1e9:.3f} GHz (wave cycles / 16 waves / item time)")
     print(f"   live pairs={cnt[7]:.0f}  survivors/pair={cnt[0]/live:.1f}  passB wave-iterations/pair={cnt[1]/live:.2f}  pairs without any open line={100*cnt[2]/live:.1f}%"
           f"  lines/pair={cnt[3]/live:.1f}  solved lines/pair={cnt[4]/live:.1f}  painted px/pair={cnt[5]/live:.1f}  lines with an open pixel in the bbox range/pair={cnt[6]/live:.1f}")

@@ -14,7 +14,21 @@ refuses the library if one is found; tests/test_build_lint.py runs it on the bui
 usage: tools/isa_lint.py [path/to/lib.so]        exit code 1 = hazardous instruction present"""
 import os, re, subprocess, sys, tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin():
+    """the LLVM tools of the ROCm installation whose hipcc builds the library (VF_LLVM_BIN overrides)"""
+    import shutil
+    cands = [os.environ.get("VF_LLVM_BIN")]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    cands += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin"), "/opt/rocm/lib/llvm/bin"]
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "llvm-objdump")) and os.path.exists(os.path.join(c, "llvm-readelf")):
+            return c
+    raise RuntimeError("llvm-objdump / llvm-readelf not found (set VF_LLVM_BIN)")
+
+
+LLVM = _llvm_bin()
 GRANULE = 8          # VGPR allocation granule of gfx90a and later (unified register file, wave64)
 HAZARD = re.compile(r"\b(v_lshlrev_b64|v_lshrrev_b64|v_ashrrev_i64)\s+v\[\d+:\d+\],\s*v(\d+)\s*,")
 

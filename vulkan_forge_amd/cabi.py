@@ -20,11 +20,11 @@ SYMBOLS = [
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_raster_groups", "vf_terrain_raster_groups", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
     "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
-    "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
+    "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_render_batch", "vf_terrain_render_batch_host", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_frame_times", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
     "vf_dist_available", "vf_dist_version", "vf_dist_unique_id", "vf_dist_comm_init", "vf_dist_comm_destroy", "vf_dist_gather_tiles", "vf_dist_gather_bands", "vf_dist_exchange_bands",
-    "vf_terrain_debug_fragment_stage",
+    "vf_terrain_debug_fragment_stage", "vf_host_alloc", "vf_host_free",
     "vf_dem_create", "vf_dem_destroy", "vf_dem_set_heights_f32", "vf_dem_set_heights_f64", "vf_dem_stats",
     "vf_dem_percentile_range", "vf_dem_normalize", "vf_dem_upload_height", "vf_dem_texture_size", "vf_dem_read_patch",
 ]
@@ -73,6 +73,8 @@ _PROTOS = {
     "vf_terrain_set_output_device": (_i, [_vp, _vp]),
     "vf_terrain_rgba_device": (_i, [_vp, C.POINTER(_vp)]),
     "vf_terrain_render": (_i, [_vp, _vp]),
+    "vf_terrain_render_batch": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "vf_terrain_render_batch_host": (_i, [_vp, _vp, _u32, _vp]),
     "vf_terrain_sync": (_i, [_vp]),
     "vf_terrain_read_rgba": (_i, [_vp, _vp, _u32, _u32]),
     "vf_terrain_read_png_scanlines": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
@@ -82,6 +84,8 @@ _PROTOS = {
     "vf_terrain_frame_times": (_i, [_vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_item_stats": (_i, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_phase_cycles": (_i, [_vp, _vp, _u32]),
+    "vf_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "vf_host_free": (None, [_vp]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
     "vf_grid_generate_device": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp, _vp]),
     "vf_triangle_render": (_i, [_vp, _u32, _u32, _vp]),
@@ -282,6 +286,23 @@ class Terrain:
     def render(self, stream=None):
         self._check(self.lib.vf_terrain_render(self.t, _vp(stream or 0)))
 
+    def render_batch(self, uniforms, outputs=None, stream=None):
+        """n poses back to back (BASELINE config 5): uniforms (n, 44) float32; outputs: n device pointers (frame k -> outputs[k]) or None."""
+        u = np.ascontiguousarray(uniforms, np.float32).reshape(-1, 44)
+        ptrs = None
+        if outputs is not None:
+            assert len(outputs) == len(u)
+            ptrs = (_vp * len(u))(*[_vp(int(p)) for p in outputs])
+        self._check(self.lib.vf_terrain_render_batch(self.t, u.ctypes.data, len(u), ptrs, _vp(stream or 0)))
+
+    def render_batch_host(self, uniforms):
+        """n poses, every frame read back: (n, H, W, 4) uint8 (pageable NumPy memory: the runtime stages the copies)."""
+        u = np.ascontiguousarray(uniforms, np.float32).reshape(-1, 44)
+        out = np.empty((len(u), self.H, self.W, 4), np.uint8)
+        ptrs = (_vp * len(u))(*[_vp(out[k].ctypes.data) for k in range(len(u))])
+        self._check(self.lib.vf_terrain_render_batch_host(self.t, u.ctypes.data, len(u), ptrs))
+        return out
+
     def sync(self):
         self._check(self.lib.vf_terrain_sync(self.t))
 
@@ -327,10 +348,10 @@ class Terrain:
         return out
 
     def phase_cycles(self):
-        """(32,) u64: [0:8] shader-clock cycles per phase summed over waves, [8:16] event counts, [16:24] parts of the set-up phase, [24:28] wave-level executions of the line loop's parts
+        """(40,) u64: [0:8] shader-clock cycles per phase summed over waves, [8:16] event counts, [16:24] parts of the set-up phase, [24:30] wave-level executions of the line loop's parts, [30:34] parts of the vertex phase
         (libraries built with -DVF_PHASE_PROF only)."""
-        out = np.zeros(32, np.uint64)
-        self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 32))
+        out = np.zeros(40, np.uint64)
+        self._check(self.lib.vf_terrain_debug_phase_cycles(self.t, out.ctypes.data, 40))
         return out
 
     def frame_times(self):

@@ -48,7 +48,7 @@ constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (powe
 #define VF_TILE_MIN_WAVES 5
 #endif
 constexpr int kMaxTileCols = 256;                 // frame width <= 16384 (vf_terrain_create)
-constexpr int kPhaseSlots = 32;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
+constexpr int kPhaseSlots = 40;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
 constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 
@@ -79,6 +79,10 @@ struct FrameParams {
     float inv2hr;                   // 1 / (2 h_range): the fast fragment path multiplies where terrain.wgsl:71 divides
     uint32_t div_m, div_s;          // cell / nm1 == mulhi(cell, div_m) >> div_s for every cell < 2^26 (host: cell_divider)
 };
+
+// Screen of this frame -> screen of the frame the plan's tile times come from, for points of the ground plane y = 0 (k_plan):
+// (x', y', w') = m * (x, y, 1) in pixels.  on = 0: the times are looked up where they were measured (camera at rest).
+struct MotionMap { float m[9]; uint32_t on; };
 
 // inclusive pixel rectangle (clamped to the target) a grid block, or a whole block row, may touch; x0 > x1 = empty
 struct PixelBox { int16_t x0, y0, x1, y1; };

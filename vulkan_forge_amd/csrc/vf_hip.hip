@@ -65,6 +65,7 @@ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 // to rank ((tx >> stripe_log2) + skew * ty) % nranks.
 uint32_t layout_skew(uint32_t layout) { return layout & 0xFFFFu; }
 uint32_t layout_shift(uint32_t layout) { return (layout >> 16) & 0xFu; }
+bool layout_valid(uint32_t layout) { return (layout >> 20) == 0u; }      // skew < 65536, stripe_log2 <= 15, nothing above
 uint32_t ilog2(uint32_t v)
 {
     uint32_t s = 0;
@@ -102,8 +103,15 @@ struct vf_terrain {
     // device state
     float *d_xs = nullptr, *d_sinx = nullptr, *d_cosz = nullptr;
     int32_t *d_txi = nullptr, *d_tyj = nullptr;
-    float *d_height_own = nullptr;
+    float *d_height_own = nullptr;       // Scene::set_height_from_r32f's copy (its own allocation: it is replaced when the size changes)
+    float *d_height_dummy = nullptr;     // the 1x1 zero texture of TerrainSpike (in the slab)
     const float *d_height = nullptr;
+    // vf_terrain_render_batch_host: a ring of device frames the poses are drawn into while earlier ones travel to the host
+    static constexpr uint32_t kBatchRing = 3;
+    uint32_t *d_batch[kBatchRing] = { nullptr, nullptr, nullptr };
+    hipEvent_t batch_drawn[kBatchRing] = { nullptr, nullptr, nullptr }, batch_copied[kBatchRing] = { nullptr, nullptr, nullptr };
+    hipStream_t copy_stream = nullptr;
+    uint8_t *slab = nullptr;             // ONE device allocation behind every fixed-size buffer of the handle (round 5: construction was ~40 hipMallocs)
     uint32_t tw = 1, th = 1;
     bool bounds_dirty = true;
     float2 *d_bounds = nullptr;          // per block: min/max displaced height
@@ -136,6 +144,10 @@ struct vf_terrain {
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
                                          // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
+        uint8_t *slab = nullptr;         // one allocation per plan state, made when the state is first used: a handle that renders ONE frame
+                                         // (the reference's usage: construct, render_png once) never pays for the second state's 0.4 GB
+        float u_used[32] = {};           // view + proj of the frame whose tile times sit in `feedback` (the plan looks them up through the camera motion)
+        bool have_u_used = false;
     } ps[kPlanStates];
     uint32_t cur_set = 0, last_set = 0;  // the set the next frame takes; the set of the frame rendered last
     const uint32_t *last_out = nullptr;  // output buffer of the frame rendered last
@@ -291,6 +303,61 @@ static AxisTables axis(const vf_terrain *t)
     return A;
 }
 
+// Buffers carved out of one device allocation, 256-byte aligned; those that must start at zero lie first and share one memset.
+namespace {
+struct Carver {
+    struct Item { void **p; size_t bytes; };
+    std::vector<Item> zeroed, plain;
+    void add(void **p, size_t bytes, bool zero = false) { (zero ? zeroed : plain).push_back({ p, (bytes + 255u) & ~(size_t)255u }); }
+    hipError_t commit(uint8_t **base, hipStream_t s)
+    {
+        size_t zero_bytes = 0, total = 0;
+        for (const Item &i : zeroed) zero_bytes += i.bytes;
+        total = zero_bytes;
+        for (const Item &i : plain) total += i.bytes;
+        hipError_t e = hipMalloc((void **)base, total);
+        if (e != hipSuccess) return e;
+        size_t off = 0;
+        for (const Item &i : zeroed) { *i.p = *base + off; off += i.bytes; }
+        for (const Item &i : plain) { *i.p = *base + off; off += i.bytes; }
+        return zero_bytes ? hipMemsetAsync(*base, 0, zero_bytes, s) : hipSuccess;
+    }
+};
+} // namespace
+
+// A plan state's buffers and events, made when the state is first used (frame 0: at construction; frame 1: by that frame).
+static hipError_t ensure_plan_state(vf_terrain *t, uint32_t k)
+{
+    vf_terrain::PlanState &S = t->ps[k];
+    if (S.slab) return hipSuccess;
+    const size_t all_tiles = (size_t)t->ntx * t->nty;
+    const size_t nsegs = (size_t)t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks);
+    Carver C;
+    C.add((void **)&S.seg_list, (nsegs + 1) * sizeof(uint32_t), true);
+    C.add((void **)&S.feedback, (all_tiles * 65 + 1) * sizeof(uint32_t), true);
+    C.add((void **)&S.background, all_tiles * sizeof(uint32_t), true);
+    C.add((void **)&S.ranges, t->nblocks * sizeof(PixelBox));
+    C.add((void **)&S.vtx, (size_t)t->nblocks * kBlockStride * sizeof(VertexRec));
+    C.add((void **)&S.recs, (size_t)t->nblocks * sizeof(BlockRec));
+    C.add((void **)&S.gen, (size_t)t->nblocks * sizeof(ulonglong2));
+    C.add((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
+    C.add((void **)&S.cap_seg, t->nblocks * sizeof(float4));
+    C.add((void **)&S.cap_rad, t->nblocks * sizeof(float));
+    C.add((void **)&S.rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
+    C.add((void **)&S.work, 2 * (all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting: as planned, and (second half) ordered
+    C.add((void **)&S.work_count, 4 * sizeof(uint32_t));
+    C.add((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
+    C.add((void **)&S.flags_new, all_tiles * sizeof(uint32_t));
+    hipError_t err = C.commit(&S.slab, t->side);          // (the state's first user is the plan chain on `side`)
+    if (err != hipSuccess) { S.slab = nullptr; return err; }
+    S.work_sorted = S.work + (all_tiles + kSplitBudget + 16);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&S.boxed, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&S.set_up, hipEventDisableTiming);
+    return err;
+}
+
 static int refresh_tables(vf_terrain *t, hipStream_t s)
 {
     hipLaunchKernelGGL(k_axis_tables, dim3((t->n + 255) / 256), dim3(256), 0, s, t->n, t->tw, t->th, t->d_xs, t->d_sinx,
@@ -328,68 +395,39 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
             lut[kLutStride * i + ch] = lut_is_srgb ? tables().decode[lut_rgba8[4 * k + ch]] : (float)lut_rgba8[4 * k + ch] / 255.0f;
         lut[kLutStride * i + 3] = 0.0f;
     }
-    const float zero = 0.0f;
-
+    // ONE device allocation for the handle's fixed-size buffers (the buffers that must start at zero lie first: one memset), one more per
+    // plan state when that state is first used (ensure_plan_state) -- construction was ~40 hipMallocs and 4 memsets (round 4: unmeasured).
     hipError_t err = hipSuccess;
-    auto A = [&](void **p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(p, bytes); };
-    A((void **)&t->d_xs, n * sizeof(float));
-    A((void **)&t->d_sinx, n * sizeof(float));
-    A((void **)&t->d_cosz, n * sizeof(float));
-    A((void **)&t->d_txi, n * sizeof(int32_t));
-    A((void **)&t->d_tyj, n * sizeof(int32_t));
-    A((void **)&t->d_height_own, sizeof(float));
-    A((void **)&t->d_bounds, t->nblocks * sizeof(float2));
-    A((void **)&t->d_hblk, (size_t)t->nblocks * kBlockStride * sizeof(float));
     const size_t all_tiles = (size_t)t->ntx * t->nty;
-    for (auto &S : t->ps) {
-        A((void **)&S.ranges, t->nblocks * sizeof(PixelBox));
-        A((void **)&S.vtx, (size_t)t->nblocks * kBlockStride * sizeof(VertexRec));
-        A((void **)&S.recs, (size_t)t->nblocks * sizeof(BlockRec));
-        A((void **)&S.gen, (size_t)t->nblocks * sizeof(ulonglong2));
-        A((void **)&S.seg_list, ((size_t)t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks) + 1) * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemset(S.seg_list, 0, ((size_t)t->nb * ((t->nb + kSegBlocks - 1) / kSegBlocks) + 1) * sizeof(uint32_t));
-        A((void **)&S.row_ranges, t->nb * sizeof(PixelBox));
-        A((void **)&S.cap_seg, t->nblocks * sizeof(float4));
-        A((void **)&S.cap_rad, t->nblocks * sizeof(float));
-        A((void **)&S.rc, 2 * (size_t)t->nb * t->ntx * sizeof(uint32_t));
-        A((void **)&S.work, 2 * (size_t)(all_tiles + kSplitBudget + 16) * sizeof(uint2));   // tiles + strips created by splitting: as planned, and (second half) ordered
-        S.work_sorted = S.work + (all_tiles + kSplitBudget + 16);
-        A((void **)&S.feedback, (all_tiles * 65 + 1) * sizeof(uint32_t));
-        A((void **)&S.work_count, 4 * sizeof(uint32_t));
-        A((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
-        A((void **)&S.background, all_tiles * sizeof(uint32_t));
-        A((void **)&S.flags_new, all_tiles * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemset(S.feedback, 0, (all_tiles * 65 + 1) * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemset(S.background, 0, all_tiles * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.drawn, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.boxed, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&S.set_up, hipEventDisableTiming);
-    }
+    Carver C;
+    C.add((void **)&t->d_height_dummy, sizeof(float), true);      // 1x1 zero texture, src/terrain/mod.rs:342-378
+    C.add((void **)&t->d_stats, (4 + 4 * (all_tiles + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t), true);   // (only [0..4) must be zero) + one bit per block: drawn this frame?
+#if VF_SLICES   // (depth slices are compiled out by default, vf_kernels.h: no merge buffer then)
+    C.add((void **)&t->d_merge, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t), true);
+#endif
+    C.add((void **)&t->d_xs, n * sizeof(float));
+    C.add((void **)&t->d_sinx, n * sizeof(float));
+    C.add((void **)&t->d_cosz, n * sizeof(float));
+    C.add((void **)&t->d_txi, n * sizeof(int32_t));
+    C.add((void **)&t->d_tyj, n * sizeof(int32_t));
+    C.add((void **)&t->d_bounds, t->nblocks * sizeof(float2));
+    C.add((void **)&t->d_hblk, (size_t)t->nblocks * kBlockStride * sizeof(float));
+    C.add((void **)&t->d_lut, sizeof lut);
+    C.add((void **)&t->d_rgba_own, all_tiles * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
+    C.add((void **)&t->d_tile_map, all_tiles * sizeof(uint32_t));
+    err = C.commit(&t->slab, ctx->stream);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side2, hipStreamNonBlocking);
-    A((void **)&t->d_lut, sizeof lut);
-    A((void **)&t->d_rgba_own, (size_t)t->ntx * t->nty * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
-    A((void **)&t->d_tile_map, (size_t)t->ntx * t->nty * sizeof(uint32_t));
-#if VF_SLICES   // (depth slices are compiled out by default, vf_kernels.h: no merge buffer then)
-    A((void **)&t->d_merge, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMemset(t->d_merge, 0, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t));
-#endif
-    A((void **)&t->d_stats, (4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t));   // + one bit per block: drawn this frame?
-    if (err == hipSuccess) err = hipMemcpy(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMemcpy(t->d_height_own, &zero, sizeof zero, hipMemcpyHostToDevice);   // 1x1 dummy, src/terrain/mod.rs:342-378
-    if (err == hipSuccess) err = hipMemset(t->d_stats, 0, 4 * sizeof(uint32_t));
-    for (int f = 0; f < vf_terrain::kTimingRing && err == hipSuccess; ++f)
-        for (int k = 0; k < 5 && err == hipSuccess; ++k) err = hipEventCreate(&t->ev[f][k]);
+    if (err == hipSuccess) err = hipMemcpyAsync(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, ctx->stream);   // (pageable source: returns when the copy is staged)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
-    for (auto &g : t->gprobe) { if (err == hipSuccess) err = hipEventCreate(&g.b); }
+    if (err == hipSuccess) err = ensure_plan_state(t, 0);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
         return fail(err == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, m);
     }
     t->d_rgba = t->d_rgba_own;
-    t->d_height = t->d_height_own; t->tw = 1; t->th = 1;
+    t->d_height = t->d_height_dummy; t->tw = 1; t->th = 1;
     int rc = refresh_tables(t, ctx->stream);
     if (rc == VF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(VF_ERR_HIP, "table setup failed");
     if (rc != VF_OK) { std::string keep = g_err; vf_terrain_destroy(t); g_err = keep; return rc; }
@@ -402,11 +440,13 @@ void vf_terrain_destroy(vf_terrain *t)
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = { t->d_xs, t->d_sinx, t->d_cosz, t->d_txi, t->d_tyj, t->d_height_own, t->d_bounds, t->d_hblk, t->d_lut, t->d_rgba_own, t->d_vis, t->d_stats, t->d_tile_map, t->d_merge, t->d_rgba_scratch, t->d_diag, t->d_xrecv, t->d_xband };
+    void *ptrs[] = { t->slab, t->d_height_own, t->d_vis, t->d_rgba_scratch, t->d_diag, t->d_xrecv, t->d_xband, t->d_batch[0], t->d_batch[1], t->d_batch[2] };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : t->batch_drawn) if (e) (void)hipEventDestroy(e);
+    for (auto &e : t->batch_copied) if (e) (void)hipEventDestroy(e);
+    if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
     for (auto &S : t->ps) {
-        void *sp[] = { S.seg_list, S.vtx, S.recs, S.gen, S.ranges, S.row_ranges, S.cap_seg, S.cap_rad, S.rc, S.work, S.work_count, S.redo, S.background, S.flags_new, S.feedback };
-        for (void *p : sp) if (p) (void)hipFree(p);
+        if (S.slab) (void)hipFree(S.slab);
         if (S.planned) (void)hipEventDestroy(S.planned);
         if (S.drawn) (void)hipEventDestroy(S.drawn);
         if (S.boxed) (void)hipEventDestroy(S.boxed);
@@ -537,8 +577,10 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     // tile numbering changed: forget the scheduling feedback of the previous layout
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
+        if (!S.slab) continue;                             // (a state not used yet starts at zero when it is made)
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
+        S.have_u_used = false;
     }
     return VF_OK;
 }
@@ -548,6 +590,7 @@ int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nran
 {
     if (!count) return fail(VF_ERR_INVALID, "NULL argument");
     if (width == 0 || height == 0 || nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "empty frame or rank >= nranks");
+    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word has bits above VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15)");
     const uint32_t ntx = (width + kTileW - 1) / kTileW, nty = (height + kTileH - 1) / kTileH;
     if (ntx > 0xFFFFu || nty > 0xFFFFu) return fail(VF_ERR_INVALID, "frame too large");
     uint32_t n = 0;
@@ -565,6 +608,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
+    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word has bits above VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15)");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     std::vector<uint32_t> map((size_t)t->ntx * t->nty);
@@ -579,8 +623,10 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->frames_since_reset = 0;
     VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
     for (auto &S : t->ps) {
+        if (!S.slab) continue;                             // (a state not used yet starts at zero when it is made)
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
         VF_HIP_TRY(hipMemset(S.background, 0, (size_t)t->ntx * t->nty * sizeof(uint32_t)));
+        S.have_u_used = false;
     }
     return VF_OK;
 }
@@ -684,6 +730,45 @@ static float camera_shift_px(const vf_terrain *t, const float *a, const float *b
     }
     return worst;
 }
+// Homography of the ground plane y = 0 from the screen of camera `now` to the screen of camera `then` (both: view u[0..16), proj
+// u[16..32), column-major; pixels): a point (X, 0, Z) of the plane projects to A G (X, Z, 1) with G the columns x, z, w / rows x, y, w
+// of proj * view and A the viewport; the map is (A G_then) (A G_now)^-1.  False when the plane is (nearly) edge-on for `now`.
+static bool motion_map(const vf_terrain *t, const float *then, const float *now, MotionMap &M)
+{
+    const double hw = 0.5 * t->W, hh = 0.5 * t->H;
+    auto plane = [&](const float *u, double g[9]) {
+        double vp[16];                                     // proj * view, column-major
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) {
+                double a = 0.0;
+                for (int k = 0; k < 4; ++k) a += (double)u[16 + 4 * k + r] * (double)u[4 * c + k];
+                vp[4 * c + r] = a;
+            }
+        const int cols[3] = { 0, 2, 3 };
+        for (int j = 0; j < 3; ++j) {
+            const double cx = vp[4 * cols[j] + 0], cy = vp[4 * cols[j] + 1], cw = vp[4 * cols[j] + 3];
+            g[0 + j] = hw * cx + hw * cw; g[3 + j] = -hh * cy + hh * cw; g[6 + j] = cw;      // row-major 3 x 3
+        }
+    };
+    double a[9], b[9];
+    plane(then, a); plane(now, b);
+    const double det = b[0] * (b[4] * b[8] - b[5] * b[7]) - b[1] * (b[3] * b[8] - b[5] * b[6]) + b[2] * (b[3] * b[7] - b[4] * b[6]);
+    double scale = 0.0;
+    for (double v : b) scale = std::fmax(scale, std::fabs(v));
+    if (!(std::fabs(det) > 1e-12 * scale * scale * scale)) return false;
+    const double inv[9] = { (b[4] * b[8] - b[5] * b[7]) / det, (b[2] * b[7] - b[1] * b[8]) / det, (b[1] * b[5] - b[2] * b[4]) / det,
+                            (b[5] * b[6] - b[3] * b[8]) / det, (b[0] * b[8] - b[2] * b[6]) / det, (b[2] * b[3] - b[0] * b[5]) / det,
+                            (b[3] * b[7] - b[4] * b[6]) / det, (b[1] * b[6] - b[0] * b[7]) / det, (b[0] * b[4] - b[1] * b[3]) / det };
+    double m[9], big = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { m[3 * r + c] = a[3 * r] * inv[c] + a[3 * r + 1] * inv[3 + c] + a[3 * r + 2] * inv[6 + c]; big = std::fmax(big, std::fabs(m[3 * r + c])); }
+    if (!(big > 0.0) || !std::isfinite(big)) return false;
+    // (homogeneous: any POSITIVE scale -- w' = w_then / w_now is positive for plane points in front of both cameras, which is what
+    //  k_plan asks of a landing point; keep the floats in range)
+    for (int k = 0; k < 9; ++k) M.m[k] = (float)(m[k] / big);
+    M.on = 1u;
+    return true;
+}
 constexpr float kFreshFeedbackPx = 24.0f;   // from here on (3/8 of a tile per frame) the plan waits for the previous frame's feedback
 
 #ifndef VF_GROUPS_MAX_RANKS
@@ -701,6 +786,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t set = t->cur_set;
     t->cur_set = (set + 1u) % vf_terrain::kPlanStates;
     t->frame_no++;
+    VF_HIP_TRY(ensure_plan_state(t, set));                                 // (a handle's second frame makes the second state)
     vf_terrain::PlanState &S = t->ps[set], &O = t->ps[t->last_set];       // this frame's plan state, the previous frame's
     // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
     // a camera that moves the picture by a good part of a tile per frame waits for the previous frame instead and uses ITS feedback:
@@ -715,8 +801,25 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // (one more frame after the motion stops: the frame before last still shows the old view, the last one the new)
     // ... and the second frame of a handle: its own plan state has no times yet, the first frame's has
     // ... and the frames of a handle whose own plan state has no times yet (the sets take turns): the previous frame's has
-    const bool fresh = t->camera_moving || t->was_moving || (t->frames_since_reset >= 1 && t->frames_since_reset < vf_terrain::kPlanStates);
-    const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");   // no tile times at all yet: a static estimate stands in (k_plan_estimate)
+    // Round 5: a moving camera's plan no longer waits either when this set's times can be looked up THROUGH the motion (k_plan,
+    // MotionMap): the homography of the ground plane between this frame's screen and the screen of the frame before last.  What is
+    // left of the waiting mode: a handle's second frame, sharded handles (their feedback is per local tile), a jump cut (the view of
+    // two frames ago shares little with this one: the previous frame's times, dilated, are the better guess), an edge-on plane.
+    const bool young = t->frames_since_reset >= 1 && t->frames_since_reset < vf_terrain::kPlanStates;
+    MotionMap M;
+    std::memset(&M, 0, sizeof M);
+    if ((t->camera_moving || t->was_moving) && !young && t->frames_since_reset >= vf_terrain::kPlanStates && S.have_u_used && t->nranks == 1u && !t->shard_tiles &&
+        camera_shift_px(t, S.u_used, t->u) < 0.4f * (float)std::max(t->W, t->H))
+        (void)motion_map(t, S.u_used, t->u, M);
+#ifdef VF_EXPERIMENTS
+    if (std::getenv("VF_NO_MOTION_MAP")) M.on = 0u;
+#endif
+    const bool fresh = young || ((t->camera_moving || t->was_moving) && !M.on);
+#ifdef VF_EXPERIMENTS
+    const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");
+#else
+    const bool first = t->frames_since_reset == 0;
+#endif   // no tile times at all yet: a static estimate stands in (k_plan_estimate)
     t->frames_since_reset++;
     const bool motion_starts = t->camera_moving && !t->was_moving;
     t->was_moving = t->camera_moving;
@@ -753,7 +856,11 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     //  share the CUs with the previous frame's tile kernel more smoothly than a few long-lived ones)
     // (experiments only, VF_DBG_NO_SETUP=1: a camera at rest re-creates the same records in the same buffers, so after the first frames
     //  the pass can be left out to see what the frame costs without it -- the picture stays right, the time is a lower bound)
+#ifdef VF_EXPERIMENTS
     static const bool dbg_no_setup = std::getenv("VF_DBG_NO_SETUP") != nullptr;
+#else
+    constexpr bool dbg_no_setup = false;
+#endif
     if (!(dbg_no_setup && t->frames_since_reset > 6))
     hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, t->side2,
                        P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen, S.seg_list, seg_count);
@@ -770,10 +877,11 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         }
         const vf_terrain::PlanState &F = fresh ? O : S;               // whose tile times steer this frame
         hipLaunchKernelGGL(k_plan, dim3(ntiles), dim3(256), 0, side, P, S.row_ranges, S.flags_new, S.work, S.work_count,
-                           F.feedback, quantum, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background);
+                           F.feedback, quantum, S.work_count + 1, rc_lo, rc_hi, dilate ? 1u : 0u, F.background, M);
         hipLaunchKernelGGL(k_plan_sort, dim3(1), dim3(256), 0, side, S.work, S.work_sorted, S.work_count, S.feedback, t->ntx * t->nty,
                            S.flags_new, S.background, ntiles);
     }
+    VF_HIP_TRY(hipGetLastError());                              // a failed plan launch is reported here: the probe block below clears hipEventQuery's "not ready"
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
@@ -784,14 +892,22 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // The previous frame may have been drawn on another stream of the caller's: this frame waits for it (same output / statistics
     // buffers; and when it went to another output buffer, letting the two tile kernels overlap costs more than it gains -- the
     // experiment behind VF_OVERLAP_FRAMES, tools/exp_overlap.py).
+#ifdef VF_EXPERIMENTS
     static const bool overlap_frames = std::getenv("VF_OVERLAP_FRAMES") != nullptr;
+#else
+    constexpr bool overlap_frames = false;
+#endif
     if (t->last_stream && t->last_stream != s && t->rendered && (!overlap_frames || t->last_out == t->d_rgba || stats || write_vis || !t->last_out))
         VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
     // line groups in the raster's line loop (vf_kernels.h, raster_fast): whole frames and shards of few ranks -- wide items, triangles
     // with many lines -- gain from them (C4: one GPU -2 %, top-down camera -7 %); a rank of many mostly draws narrow strips, whose
     // triangles have a handful of lines, and is better off with the leaner kernel (VF_GROUPS=0 / 1 overrides)
+#ifdef VF_EXPERIMENTS
     static const int groups_env = std::getenv("VF_GROUPS") ? std::atoi(std::getenv("VF_GROUPS")) : -1;
+#else
+    constexpr int groups_env = -1;
+#endif
     const int forced = groups_env >= 0 ? groups_env : t->groups_mode;
     // the variant by default: groups for whole frames and shards of few ranks, none for a rank of many (mostly narrow strips)
     const int guess = t->nranks < (uint32_t)VF_GROUPS_MAX_RANKS ? 1 : 0;
@@ -837,6 +953,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 3u && e_now < 16u) || e_now % 128u >= 124u);
     vf_terrain::GroupProbe *gp = nullptr;
     if (probe) { gp = &t->gprobe[t->gprobe_head++ % 16]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
+    if (gp && !gp->b && hipEventCreate(&gp->b) != hipSuccess) { gp->b = nullptr; gp = nullptr; }   // (made on first use: a one-shot handle never probes)
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
         hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats, seg_count);
@@ -868,6 +985,8 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipEventRecord(S.drawn, s));
     VF_HIP_TRY(hipGetLastError());
+    std::memcpy(S.u_used, t->u, sizeof S.u_used);           // the camera this set's tile times (being measured now) belong to
+    S.have_u_used = true;
     t->last_stream = s;
     t->last_set = set;
     t->last_out = t->d_rgba;
@@ -884,6 +1003,66 @@ int vf_terrain_render(vf_terrain *t, void *stream)
     t->shade_mode_frame = t->shade_mode; t->precision_frame = t->precision;
     t->have_frame = true;
     return render_impl(t, stream ? (hipStream_t)stream : t->ctx->stream, false);
+}
+
+int vf_terrain_render_batch(vf_terrain *t, const float *uniforms, uint32_t n, void *const *dev_rgba, void *stream)
+{
+    if (!t || (!uniforms && n)) return fail(VF_ERR_INVALID, "NULL argument");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (dev_rgba && !dev_rgba[k]) return fail(VF_ERR_INVALID, "dev_rgba holds a NULL output buffer");
+        std::memcpy(t->u, uniforms + 44u * k, sizeof t->u);
+        t->have_uniforms = true;
+        if (dev_rgba) t->d_rgba = (uint32_t *)dev_rgba[k];
+        std::memcpy(t->u_frame, t->u, sizeof t->u_frame);
+        t->shade_mode_frame = t->shade_mode; t->precision_frame = t->precision;
+        t->have_frame = true;
+        const int rc = render_impl(t, s, false);
+        if (rc != VF_OK) return rc;
+    }
+    return VF_OK;
+}
+
+int vf_terrain_render_batch_host(vf_terrain *t, const float *uniforms, uint32_t n, uint8_t *const *host_rgba)
+{
+    if (!t || !uniforms || !host_rgba) return fail(VF_ERR_INVALID, "NULL argument");
+    if (t->shard_tiles || t->local_rows != t->H) return fail(VF_ERR_INVALID, "batch read-back needs the whole frame on one handle (pose-parallel ranks are replicas)");
+    for (uint32_t k = 0; k < n; ++k) if (!host_rgba[k]) return fail(VF_ERR_INVALID, "host_rgba holds a NULL destination");
+    VF_HIP_TRY(hipSetDevice(t->ctx->device));
+    constexpr uint32_t R = vf_terrain::kBatchRing;
+    const size_t frame_bytes = (size_t)t->W * t->H * 4, slot_bytes = (size_t)t->ntx * t->nty * kTileW * kTileH * 4;
+    if (!t->copy_stream) VF_HIP_TRY(hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking));
+    for (uint32_t r = 0; r < R && r < n; ++r) {
+        if (!t->d_batch[r]) VF_HIP_TRY(hipMalloc(&t->d_batch[r], slot_bytes));
+        if (!t->batch_drawn[r]) VF_HIP_TRY(hipEventCreateWithFlags(&t->batch_drawn[r], hipEventDisableTiming));
+        if (!t->batch_copied[r]) VF_HIP_TRY(hipEventCreateWithFlags(&t->batch_copied[r], hipEventDisableTiming));
+    }
+    hipStream_t s = t->ctx->stream;
+    uint32_t *const out_before = t->d_rgba;
+    int rc = VF_OK;
+    hipError_t err = hipSuccess;
+    for (uint32_t k = 0; k < n && rc == VF_OK && err == hipSuccess; ++k) {
+        const uint32_t r = k % R;
+        if (k >= R) err = hipStreamWaitEvent(s, t->batch_copied[r], 0);       // pose k - R has left the slot
+        if (err != hipSuccess) break;
+        rc = vf_terrain_render_batch(t, uniforms + 44u * k, 1, (void *const *)&t->d_batch[r], s);
+        if (rc != VF_OK) break;
+        err = hipEventRecord(t->batch_drawn[r], s);
+        if (err == hipSuccess) err = hipStreamWaitEvent(t->copy_stream, t->batch_drawn[r], 0);
+        // (a pinned destination -- vf_host_alloc -- makes this one asynchronous DMA under the next pose's kernels; a pageable one is
+        //  staged by the runtime and holds the host until it is done: correct, slower)
+        if (err == hipSuccess) err = hipMemcpyAsync(host_rgba[k], t->d_batch[r], frame_bytes, hipMemcpyDeviceToHost, t->copy_stream);
+        if (err == hipSuccess) err = hipEventRecord(t->batch_copied[r], t->copy_stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(t->copy_stream);
+    const hipError_t e3 = hipStreamSynchronize(s);
+    t->d_rgba = out_before;
+    t->rendered = false;                                    // the handle's own output buffer does not hold the last pose: read-backs must render first
+    if (rc != VF_OK) return rc;
+    if (err != hipSuccess) return fail(VF_ERR_HIP, std::string("batch read-back: ") + hipGetErrorString(err));
+    if (e2 != hipSuccess || e3 != hipSuccess) return fail(VF_ERR_HIP, std::string("batch read-back: ") + hipGetErrorString(e2 != hipSuccess ? e2 : e3));
+    return VF_OK;
 }
 
 // Re-render the frame vf_terrain_render drew last with the visibility store enabled, into scratch buffers: uniforms set since,
@@ -940,9 +1119,16 @@ static unsigned copy_threads()
 // spread over a few threads).  The calling thread only orchestrates: it enqueues a chunk once every thread is done with the
 // chunk that used the slot before.  The ring is owned by the handle: nothing is allocated or registered per call (the
 // reference maps a fresh buffer per call, src/terrain/mod.rs:446-451).
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // (ordinary pageable memory: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
-    if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
+    // a destination in pinned host memory (vf_host_alloc, or the caller's own hipHostMalloc / hipHostRegister): one DMA, nothing to stage
+    if (n < kStageChunk || is_pinned_host(dst)) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
     if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, kStageSlots * kStageChunk, hipHostMallocDefault));
     for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
@@ -998,6 +1184,16 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
     return copy_to_host_staged(t, dst, (const uint8_t *)(t->d_rgba + (size_t)y0 * t->W), (size_t)rows * t->W * 4,
                                t->last_stream ? t->last_stream : t->ctx->stream);
 }
+
+int vf_host_alloc(size_t bytes, void **host)
+{
+    if (!host || bytes == 0) return fail(VF_ERR_INVALID, "NULL argument or zero size");
+    *host = nullptr;
+    hipError_t e = hipHostMalloc(host, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *host = nullptr; return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return VF_OK;
+}
+void vf_host_free(void *host) { if (host) (void)hipHostFree(host); }
 
 int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines, size_t *nbytes)
 {
@@ -1137,6 +1333,10 @@ int vf_terrain_debug_phase_cycles(vf_terrain *t, uint64_t *dst, uint32_t n)
 int vf_terrain_enable_timing(vf_terrain *t, int enable)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
+    if (enable != 0 && !t->ev[0][0]) {                      // the event ring is made when timing is first asked for
+        VF_HIP_TRY(hipSetDevice(t->ctx->device));
+        for (auto &f : t->ev) for (auto &e : f) VF_HIP_TRY(hipEventCreate(&e));
+    }
     t->timing = enable != 0;
     t->stats_on = enable == 1;   // 2: HIP events only -- the tile kernel runs exactly as it does untimed (no per-item statistics)
     t->timed_frames = 0;     // (re)start the averaging window

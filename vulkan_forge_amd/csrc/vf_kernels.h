@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                                               uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                               const uint32_t *__restrict__ last_blocks, const uint32_t *__restrict__ last_mean,
                                               uint32_t *__restrict__ split_budget, const uint32_t *__restrict__ rc_lo,
-                                              const uint32_t *__restrict__ rc_hi, uint32_t moving, const uint32_t *last_flags)
+                                              const uint32_t *__restrict__ rc_hi, uint32_t moving, const uint32_t *last_flags, MotionMap M)
 {
     __shared__ uint32_t s_hits, s_est;
     int32_t px_lo, px_hi, py_lo, py_hi;
@@ -1195,7 +1195,33 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             };
             uint32_t seen = tile_time(blockIdx.x);
             const uint32_t mean = *last_mean;
-            if ((seen == 0u || moving) && mean && P.nranks == 1u && !P.shard_tiles) {
+            bool own_time = true;                          // `seen` is this very tile's time (its pieces' times then apply too)
+            if (M.on && as_one) {
+                // MOTION-COMPENSATED FEEDBACK (round 5).  The tile times were measured under another camera (the frame before last of a
+                // moving camera): where on THAT screen was what this tile shows now?  The host hands over the homography of the ground
+                // plane y = 0 between the two screens; the tile's centre goes through it, and the tile takes the heaviest time within one
+                // tile of where it lands (the silhouette's tiles show terrain above the plane: they land a little off).  The plan of a
+                // moving camera therefore no longer waits for the previous frame's times (vf_hip.hip, render_impl): it runs under the
+                // previous frame's tile kernel like a resting camera's.  Scheduling only -- never a pixel.
+                const float cx = 0.5f * (float)(px_lo + px_hi + 1), cy = 0.5f * (float)(py_lo + py_hi + 1);
+                const float ox = fmaf(M.m[0], cx, fmaf(M.m[1], cy, M.m[2])), oy = fmaf(M.m[3], cx, fmaf(M.m[4], cy, M.m[5])), ow = fmaf(M.m[6], cx, fmaf(M.m[7], cy, M.m[8]));
+                seen = 0u; own_time = false;
+                if (ow > 1e-6f) {
+                    const float fx = ox / ow, fy = oy / ow;
+                    if (fx > -64.0f && fy > -64.0f && fx < (float)P.W + 64.0f && fy < (float)P.H + 64.0f) {
+                        // (measured on the C5 orbit, tools/exp_c5.py: the heaviest of 3 x 3 tiles 0.302 ms per pose; the heaviest of the 2 x 2 nearest
+                        //  0.372, their bilinear mean 0.42 -- under-cutting a heavy tile costs the frame's critical path; 5 x 5 or the
+                        //  times scaled up 1.5 .. 3 x: 0.306 .. 0.32; the waiting plan of round 4: 0.321)
+                        const int32_t tx = (int32_t)floorf(fx * (1.0f / kTileW)), ty = (int32_t)floorf(fy * (1.0f / kTileH));
+                        for (int32_t dy = -1; dy <= 1; ++dy)
+                            for (int32_t dx = -1; dx <= 1; ++dx) {
+                                const int32_t x = tx + dx, y = ty + dy;
+                                if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, tile_time((uint32_t)y * P.ntx + (uint32_t)x));
+                            }
+                    }
+                }
+            }
+            else if ((seen == 0u || moving) && mean && P.nranks == 1u && !P.shard_tiles) {
                 // The camera moved.  A tile that is busy now but was background in the frame the feedback comes from would sort last
                 // and never be split, and what moved in is most likely what a neighbour held (the silhouette's heavy tiles
                 // wander): it takes the heaviest tile within two tiles' distance.  With a fast camera (`moving`: the plan runs
@@ -1248,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             // hands every piece the time that piece took then (pieces differ: the slice in front draws more than the one behind,
             // the strip over the ridge more than its neighbour); cut differently, the tile's time is shared evenly.
             const uint32_t cut = lg | (lgs << 4);
-            const bool same_cut = seen == tile_time(blockIdx.x) && seen != 0u && ((last_flags[blockIdx.x] >> 8) & 0x3Fu) == cut;
+            const bool same_cut = own_time && seen == tile_time(blockIdx.x) && seen != 0u && ((last_flags[blockIdx.x] >> 8) & 0x3Fu) == cut;
             const uint32_t *piece_time = last_blocks + (size_t)P.ntx * P.nty + 1u + (size_t)blockIdx.x * 64u;
             flags_out[blockIdx.x] = cut << 8;               // busy; the pieces it is cut into (read back with its time, two frames on)
             const uint32_t parts = 1u << lg, slices = 1u << lgs;
@@ -1365,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_plan_sort(const uint2 *__restrict__ wor
 //      conservative); a fully final tile stops early;
 //   5. fragment stage on the LDS tile.
 #ifdef VF_PHASE_PROF   // diagnostics build: per-phase shader-clock cycles and event counts (vf_terrain_debug_phase_cycles)
-#define VF_PH_INIT uint64_t ph_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..15: parts of the set-up; 16, 17: parts of `vertex`
+#define VF_PH_INIT uint64_t ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..15: parts of the set-up; 16, 17: parts of `vertex`
 #define VF_PH(p) { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[p] += ph_now - ph_last; ph_last = ph_now; }
 #else
 #define VF_PH_INIT
@@ -1778,8 +1804,16 @@ next_item:
                 const uint32_t rflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_lo.z);
                 VF_PH(16)                                  // (diagnostics: the record is here)
                 VF_PH(17)                                  // (diagnostics: nothing in between -- what one time stamp costs)
+#ifdef VF_PHASE_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                VF_PH(18)                                  // (diagnostics: the vertex records are here)
+#endif
                 sXY[wave][lane] = xa;
                 if (lane < (uint32_t)(kNV - 64)) sXY[wave][64u + lane] = xb;
+#ifdef VF_PHASE_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                VF_PH(19)                                  // (diagnostics: ... and staged in LDS)
+#endif
                 if (!COMPLETE && (rflags & kRecGeneric)) { if (lane == 0) s_redo = 1u; }   // rare: clipped / oversized -> the COMPLETE launch
                 // the alive primitives as a dense list: cell c's even primitive sits at popcount(alive_e below c), its odd one behind all
                 // the even ones -- every lane of the classification below then holds a primitive that can draw
@@ -2062,6 +2096,7 @@ next_item:
             for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
             for (int p = 8; p < 16; ++p) atomicAdd(&ph[8 + p], (unsigned long long)ph_acc[p]);
             atomicAdd(&ph[30], (unsigned long long)ph_acc[16]); atomicAdd(&ph[31], (unsigned long long)ph_acc[17]);
+            atomicAdd(&ph[32], (unsigned long long)ph_acc[18]); atomicAdd(&ph[33], (unsigned long long)ph_acc[19]);
             atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
             atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
         }

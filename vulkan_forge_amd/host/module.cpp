@@ -85,6 +85,48 @@ vf_ctx *global_ctx()
     return ctx.c;
 }
 
+// ---- frame-sized read-back buffers in page-locked host memory (round 5) ---------------------------------------------------------
+// render_rgba returns a NumPy array OVER such a buffer instead of copying the frame into fresh pageable memory: the device writes it
+// with one DMA transfer (C4: 64 MiB in 1.2 ms) where the staged copy into untouched pages was page-fault bound (2-5 ms; the
+// reference maps a fresh buffer per call, src/terrain/mod.rs:446-451).  The array owns its buffer through a capsule; when the array
+// dies the buffer goes back to the pool, so a render loop alternates between two buffers and never allocates again.
+class PinnedPool {
+public:
+    static PinnedPool &get() { static PinnedPool *p = new PinnedPool; return *p; }   // (process lifetime: never destroyed, like the context)
+    void *take(size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < idle.size(); ++k)
+                if (idle[k].second == bytes) { void *p = idle[k].first; idle.erase(idle.begin() + (long)k); return p; }
+        }
+        void *p = nullptr;
+        check(vf_host_alloc(bytes, &p));
+        return p;
+    }
+    void give(void *p, size_t bytes)
+    {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            idle.emplace_back(p, bytes);
+            size_t held = 0;
+            for (auto &b : idle) held += b.second;
+            while (idle.size() > kMaxIdle || held > kMaxIdleBytes) { held -= idle.front().second; drop.push_back(idle.front().first); idle.erase(idle.begin()); }
+        }
+        for (void *d : drop) vf_host_free(d);
+    }
+private:
+    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30;
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> idle;
+};
+struct PinnedLease { void *p; size_t bytes; };
+py::capsule pinned_owner(void *p, size_t bytes)
+{
+    return py::capsule(new PinnedLease{ p, bytes }, [](void *v) { auto *l = static_cast<PinnedLease *>(v); PinnedPool::get().give(l->p, l->bytes); delete l; });
+}
+
 // PyO3's `&mut self` borrow (Threading): a method entered while another thread is inside one of the same object
 // raises RuntimeError("Already borrowed") instead of racing.  It matters here because render / read-back release the GIL:
 // per-handle state (plan sets, pinned read-back buffers, frame counters) is not synchronised below the C-ABI ("calls on one
@@ -220,9 +262,62 @@ public:
         Borrow b(busy);
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
-        py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
-        render_into(a.mutable_data(), rows);                   // straight into the array: no intermediate copy
-        return a;
+        const size_t bytes = (size_t)rows * W * 4;
+        if (bytes < ((size_t)4 << 20) || std::getenv("VF_RGBA_PAGEABLE")) {     // small frames: an ordinary array, one direct copy
+            py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
+            render_into(a.mutable_data(), rows);
+            return a;
+        }
+        // frame-sized: the array lives in page-locked memory from the pool (above) -- one DMA transfer, no host copy
+        void *p = PinnedPool::get().take(bytes);
+        py::capsule owner = pinned_owner(p, bytes);             // (returns the buffer if anything below throws)
+        render_into(static_cast<uint8_t *>(p), rows);
+        return py::array_t<uint8_t>({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 }, static_cast<uint8_t *>(p), owner);
+    }
+    // extension (BASELINE config 5, "batch of camera look-ats over one terrain"): every pose is what set_camera_look_at + render
+    // does per pose (src/scene/mod.rs:208-224, :278-335), queued back to back on the GPU; poses = sequence of
+    // (eye, target, up, fovy_deg, znear, zfar).  Returns the frames as a list of (H, W, 4) uint8 arrays, or -- with `paths`, one per
+    // pose -- writes PNG files and returns None.  The camera afterwards is the last pose's, as after the per-pose loop.
+    py::object render_batch(py::sequence poses, py::object paths)
+    {
+        Borrow b(busy);
+        uint32_t rows = 0;
+        check(vf_terrain_local_rows(t, &rows));
+        if (rows != H) throw std::runtime_error("render_batch needs the whole frame on one object (a band shard renders its rows with render_rgba)");
+        const size_t n = (size_t)py::len(poses);
+        std::vector<std::string> files;
+        if (!paths.is_none()) {
+            files = paths.cast<std::vector<std::string>>();
+            if (files.size() != n) throw py::value_error("paths must hold one file name per pose");
+        }
+        const float aspect = (float)W / (float)H;
+        std::vector<float> blocks(44 * n);
+        Mat4 v{}, p{};
+        for (size_t k = 0; k < n; ++k) {
+            auto pose = poses[k].cast<std::tuple<std::tuple<float, float, float>, std::tuple<float, float, float>, std::tuple<float, float, float>, float, float, float>>();
+            validate_camera_params(v3(std::get<0>(pose)), v3(std::get<1>(pose)), v3(std::get<2>(pose)), std::get<3>(pose), std::get<4>(pose), std::get<5>(pose));
+            v = look_at_rh(v3(std::get<0>(pose)), v3(std::get<1>(pose)), v3(std::get<2>(pose)));
+            p = perspective_wgpu(to_radians(std::get<3>(pose)), aspect, std::get<4>(pose), std::get<5>(pose));
+            const Uniforms u = to_uniforms(globals, v, p);
+            std::memcpy(blocks.data() + 44 * k, u.data(), 44 * sizeof(float));
+        }
+        if (n == 0) return files.empty() && paths.is_none() ? py::object(py::list()) : py::object(py::none());
+        const size_t bytes = (size_t)H * W * 4;
+        std::vector<py::capsule> owners;
+        std::vector<uint8_t *> dst(n);
+        for (size_t k = 0; k < n; ++k) { void *q = PinnedPool::get().take(bytes); owners.push_back(pinned_owner(q, bytes)); dst[k] = static_cast<uint8_t *>(q); }
+        {
+            py::gil_scoped_release nogil;
+            const int rc = vf_terrain_render_batch_host(t, blocks.data(), (uint32_t)n, dst.data());
+            if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
+            for (size_t k = 0; k < files.size(); ++k) write_png_rgba8(files[k], dst[k], W, H);
+        }
+        view = v; proj = p;                                     // the camera of the last pose stays, as after a loop of set_camera_look_at
+        push_uniforms();
+        if (!files.empty()) return py::none();
+        py::list frames;
+        for (size_t k = 0; k < n; ++k) frames.append(py::array_t<uint8_t>({ (py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)4 }, dst[k], owners[k]));
+        return frames;
     }
     // extension: visible primitive id + 1 per pixel of the last render (0 = background)
     py::array_t<uint32_t> debug_visibility()
@@ -547,6 +642,7 @@ py::class_<T> bind_terrain(py::module_ &m, const char *name)
              py::arg("colormap") = "viridis")
         .def("render_png", &T::render_png, py::arg("path"))
         .def("render_rgba", &T::render_rgba)
+        .def("render_batch", &T::render_batch, py::arg("poses"), py::arg("paths") = py::none())
         .def("set_camera_look_at", &T::set_camera_look_at, py::arg("eye"), py::arg("target"), py::arg("up"), py::arg("fovy_deg"),
              py::arg("znear"), py::arg("zfar"))
         .def("debug_uniforms_f32", &T::debug_uniforms_f32)
