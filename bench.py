@@ -143,6 +143,17 @@ def host_cpus():
     return os.cpu_count() or 1, aff, quota, model
 
 
+def toolchain():
+    """the compiler the library in use was (or would be) built with, and its code-generation switches -- a compiler bump shows up here"""
+    try:
+        import __graft_entry__ as g
+        v = subprocess.run([g._hipcc(), "--version"], capture_output=True, text=True, timeout=30).stdout.splitlines()
+        keep = [ln.strip() for ln in v if ln.startswith("HIP version") or "clang version" in ln]
+        return {"hipcc": "; ".join(keep) or (v[0] if v else None), "tuning_flags": " ".join(g.HIPCC_TUNING)}
+    except Exception as e:  # noqa: BLE001
+        return {"hipcc": None, "error": repr(e)}
+
+
 def lib_sha256(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -604,6 +615,7 @@ def main():
             # faster per view: vf_terrain_set_raster_groups) and what its probes measured: the frame period (end of one frame's work on the
             # draw stream to the end of the next, both drawn by the same variant), per variant
             "raster_line_loop": {"with_line_groups": bool(tm["raster_groups"][0]), "frame_period_ms_probed": {"plain": tm["raster_groups"][1][0], "groups": tm["raster_groups"][1][1]}},
+            "build": toolchain(),
             "roofline": roofline,
             "roofline_fragment": frag,
             "cpu_baseline": cpu,

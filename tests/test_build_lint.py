@@ -33,3 +33,27 @@ def test_the_lint_finds_the_form_in_the_hardware_probe(tmp_path):
     assert checked >= 12
     assert len(found) == 7, names                    # shl/lshr/ashr of v15, and shl of v23, v31, v63, v127
     assert not any("v14" in k or "sub" in k or "mad" in k or "cvt" in k for k in names), names
+
+
+def test_the_tile_kernel_keeps_the_properties_its_build_flags_buy():
+    """The frame time rests on eight code-generation switches (__graft_entry__.HIPCC_TUNING) that keep the tile kernel's main
+    instantiations inside 96 vector registers with next to no scratch traffic (at 128 registers the next frame's
+    set-up pass no longer fits beside it, +12 %; a reload per pulled block cost 2-6 %).  A compiler bump that silently loses them fails
+    HERE instead of in a benchmark: for k_tile<*, COMPLETE = false, FAST = true, *> -- the launches that draw the frames --
+    VGPRs <= 96, scratch <= 28 bytes per lane, and no scratch access inside the chunk loop or below it (loop depth >= 2: the block
+    pull loop, pass A / B, the line loop, painting)."""
+    import isa_stats                                  # recompiles vf_hip.hip with the build's flags + --save-temps (about 30 s)
+    _text, records, depths = isa_stats.collect()
+    mains = {k: v for k, v in records.items() if k.startswith("k_tile<") and k.split(", ")[1] == "false" and k.split(", ")[2] == "true"}
+    assert len(mains) == 4, sorted(records)
+    for name, nt in mains.items():
+        assert int(nt["NumVgprs"]) <= 96, (name, nt)
+        assert int(nt["ScratchSize"]) <= 28, (name, nt)
+        assert int(nt["Occupancy"]) >= 5, (name, nt)
+        assert int(nt["LDSByteSize"]) <= 81920, (name, nt)       # half a CU's LDS: beyond it the register budget is silently dropped
+    assert set(depths) == {"k_tile<false, false, true, true>", "k_tile<false, false, true, false>"}
+    for name, hist in depths.items():
+        deep = {k: n for k, n in hist.items() if k[0] >= 2}
+        assert not deep, f"{name}: scratch accesses inside the chunk loop or below: {deep}"
+    # the set-up pass must fit beside the tile kernel: 512 - 4 waves x 96 registers leave 128 per SIMD
+    assert int(records["k_block_setup"]["NumVgprs"]) <= 64, records["k_block_setup"]

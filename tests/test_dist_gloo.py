@@ -202,7 +202,8 @@ def _band_worker(rank, world, port, W, H, G, q, stripe=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,stripe", [(2, 256, 128, 0), (4, 256, 256, 0), (2, 512, 128, 2), (4, 512, 256, 1)])
+# (8, 512, 512, 0): the layout of the driver's 8-GPU run in small -- single-column stripes, eight bands of whole tile rows, 64-tile frame
+@pytest.mark.parametrize("world,W,H,stripe", [(2, 256, 128, 0), (4, 256, 256, 0), (2, 512, 128, 2), (4, 512, 256, 1), (8, 512, 512, 0)])
 def test_tile_shards_band_stitch_exchange(world, W, H, stripe):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -268,8 +268,11 @@ def test_frame_sized_render_rgba_arrays_live_in_the_pinned_pool(oracle, luts, mo
     import gc
     W, H, G = 1920, 1080, 256
     s = vf.TerrainSpike(W, H, grid=G, colormap="viridis")
+    first = s.render_rgba()                                      # an object's first frame: an ordinary array (no page-locking for one frame)
+    assert first.flags["OWNDATA"]
     a = s.render_rgba()
     b = s.render_rgba()
+    assert np.array_equal(first, a)
     assert a.shape == (H, W, 4) and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"] and not a.flags["OWNDATA"]
     assert a.ctypes.data != b.ctypes.data and np.array_equal(a, b)
     ref, _ = oracle.render_terrain(oracle.default_uniforms(0, W, H), W, H, G, oracle.SPIKE_DUMMY_HEIGHT, luts["viridis"], nthreads=min(16, oracle.max_threads()), want_vis=False)

@@ -108,3 +108,18 @@ def test_rccl_gather_through_the_c_abi(oracle, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VF_ROOT=root, VF_UNIFORMS=str(upath), VF_UNIFORMS2=str(upath2))
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "CABI GATHER OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_eight_virtual_ranks_rehearse_the_drivers_n8_frame():
+    """The driver's `bench.py --gpus 8` layout at C4 size -- stripe_log2 0, eight bands of eight tile rows, 64-tile chunks -- as eight
+    handles of ONE process (tools/rehearse_virtual.py: the pool's process guard allows six GPU processes per card, so the N = 8
+    path cannot be rehearsed as processes): sharding, slabs, chunked all-to-all, per-rank band stitch, in-place gather; the stitched
+    frame equals the single-rank frame byte for byte."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rehearse_virtual.py"), "8", "--frames", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 8 and len(d["ranks"]) == 8 and d["gathered_frame_equals_single_rank_frame"] is True
+    assert d["stripe_log2"] == 0 and d["band_rows"] == 512 and d["chunk_tiles"] == 64
+    assert all(rk["local_tiles"] == 512 for rk in d["ranks"])

@@ -32,6 +32,7 @@ with tempfile.TemporaryDirectory() as tmp:
     t0 = time.perf_counter(); a.set_height_from_r32f(heights); out["set_height"] = ms(t0)
     t0 = time.perf_counter(); a.render_png(png); out["first_render_png"] = ms(t0)
     t0 = time.perf_counter(); a.render_png(png); out["second_render_png"] = ms(t0)
+    t0 = time.perf_counter(); a.render_png(png); out["third_render_png"] = ms(t0)
     out["png_bytes"] = os.path.getsize(png)
     del a
     # a second object of the same process (the runtime is warm): what its first frame costs as an array
@@ -39,6 +40,8 @@ with tempfile.TemporaryDirectory() as tmp:
     t0 = time.perf_counter(); b.set_height_from_r32f(heights); out["set_height_second_object"] = ms(t0)
     t0 = time.perf_counter(); rgba = b.render_rgba(); out["first_render_rgba"] = ms(t0)
     t0 = time.perf_counter(); rgba2 = b.render_rgba(); out["second_render_rgba"] = ms(t0)
+    t0 = time.perf_counter(); rgba3 = b.render_rgba(); out["third_render_rgba"] = ms(t0)
+    t0 = time.perf_counter(); rgba3 = b.render_rgba(); out["fourth_render_rgba"] = ms(t0)
     out["frames_equal"] = bool(np.array_equal(rgba, rgba2))
     out["covered_fraction"] = float((rgba.reshape(-1, 4) != rgba[0, 0]).any(axis=1).mean())
     t0 = time.perf_counter(); del b; out["destroy"] = ms(t0)

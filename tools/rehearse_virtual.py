@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Dress rehearsal of the N-rank C4 frame with N VIRTUAL ranks in ONE process on one GPU.
+
+The driver's 8-GPU command is `bench.py --gpus 8`: one process per GPU.  `bench.py --gpus N --rehearse` runs the same N processes on
+one GPU over gloo -- for N <= 6, the most processes the GPU pool lets one user put on a card (its process guard kills the run beyond
+that), so the N = 8 path -- single-column stripes (stripe_log2 0), eight bands of eight tile rows, chunks of 64 tiles -- cannot be
+rehearsed that way.  Here the N ranks are N handles of one process, every rank sharded exactly as bench.py shards it
+(vdist.default_stripe_log2 / layout_code, vf_terrain_set_tile_shard), and the exchange is bench.py's BandStitchExchange with its two
+collectives replaced by the device copies they amount to:
+
+    all-to-all   chunk b of rank r's slab  ->  slot r of rank b's receive buffer
+    stitch       every rank stitches its band with vf_stitch_tiles_device (the very call bench.py makes)
+    gather       band b  ->  rows [b H/N, (b+1) H/N) of the image
+
+The stitched frame must equal a single-rank render byte for byte.  torch.distributed itself at world size 8 is covered on the CPU
+(tests/test_dist_gloo.py, gloo) and the RCCL calls by the one-rank communicator tests; what has no rehearsal is xGMI.
+Prints one JSON line shaped like bench.py's N > 1 line (`ranks` has N entries); exit code 3 when the frames differ.
+
+usage: rehearse_virtual.py [N=8] [--camera default|fill] [--frames 12]"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ap = argparse.ArgumentParser()
+ap.add_argument("n", nargs="?", type=int, default=8)
+ap.add_argument("--camera", default="default")
+ap.add_argument("--frames", type=int, default=12)
+ap.add_argument("--size", type=int, default=4096)
+args = ap.parse_args()
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402  (first: one HIP runtime per process)
+import vulkan_forge_amd as vf   # noqa: E402
+from vulkan_forge_amd import cabi, dist as vdist   # noqa: E402
+import importlib.util   # noqa: E402
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+
+N, W, H, G = args.n, args.size, args.size, args.size
+dev = torch.device("cuda", 0)
+lut = vf.colormap_rgba8("viridis")
+heights = torch.from_numpy(np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)).to(dev)
+u = b.camera_uniforms(args.camera, W, H)
+stripe = vdist.default_stripe_log2(N, (W + 63) // 64)
+assert vdist.band_exchange_applies(W, H, N, stripe), "the band exchange needs stripes and bands that divide evenly"
+layout = vdist.layout_code(0, stripe)
+ntx, nty = W // 64, H // 64
+chunk_tiles = (nty // N) * (ntx // N)
+stride = chunk_tiles * N
+band_rows = H // N
+words = vdist.TILE_WORDS
+
+ranks = []
+for r in range(N):
+    t = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=0)
+    t.set_height_device(heights.data_ptr(), G, G)
+    t.set_tile_shard(r, N, layout)
+    assert t.local_tiles() == len(vdist.tile_layout(W, H, r, N, layout)) == stride
+    slab = torch.zeros(stride * words, dtype=torch.int32, device=dev)
+    t.set_output_device(slab.data_ptr())
+    t.set_uniforms(u)
+    ranks.append({"t": t, "slab": slab, "recv": torch.zeros((N, chunk_tiles * words), dtype=torch.int32, device=dev),
+                  "band": torch.zeros((band_rows, W, 4), dtype=torch.uint8, device=dev)})
+image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+stream = torch.cuda.ExternalStream(ranks[0]["t"].stream_handle(), device=dev)      # every handle of the process shares the context's stream
+torch.cuda.set_stream(stream)
+
+
+def frame():
+    for R in ranks:
+        R["t"].render(stream.cuda_stream)
+    for r, R in enumerate(ranks):                                     # all-to-all: chunk b of rank r -> slot r of rank b
+        chunks = R["slab"].view(N, chunk_tiles * words)
+        for bnd in range(N):
+            ranks[bnd]["recv"][r].copy_(chunks[bnd], non_blocking=True)
+    for bnd, R in enumerate(ranks):                                   # every rank stitches its band, the root gathers them in place
+        R["t"].stitch_tiles(R["recv"].data_ptr(), R["band"].data_ptr(), N, layout, chunk_tiles, stream.cuda_stream, height=band_rows)
+        image[bnd * band_rows:(bnd + 1) * band_rows].copy_(R["band"], non_blocking=True)
+
+
+for _ in range(args.frames):
+    frame()
+torch.cuda.synchronize()
+# what one rank costs on its own: steady-state frame period, one rank after another (the other ranks idle)
+periods = []
+for R in ranks:
+    for _ in range(8):
+        R["t"].render(stream.cuda_stream)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        R["t"].render(stream.cuda_stream)
+    torch.cuda.synchronize(); periods.append((time.perf_counter() - t0) / 20 * 1e3)
+frame()
+torch.cuda.synchronize()
+got = image.clone()
+single = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=0)
+single.set_height_device(heights.data_ptr(), G, G); single.set_uniforms(u); single.set_output_device(image.data_ptr())
+for _ in range(10):
+    single.render(stream.cuda_stream)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    single.render(stream.cuda_stream)
+torch.cuda.synchronize(); one_gpu = (time.perf_counter() - t0) / 20 * 1e3
+equal = bool(torch.equal(got, image))
+di = ranks[0]["t"].device_info()
+out = {"rehearsal": f"{N} virtual ranks in one process on one GPU (the pool allows at most 6 GPU processes per card): sharding, slabs, chunked all-to-all, "
+                    "per-rank band stitch and in-place band gather as bench.py --gpus N runs them, the two collectives as device copies; not a performance number",
+       "n_gpus": N, "config": {"workload": f"C4: Scene {W}x{H}, grid={G}, {args.camera} camera", "parallelism":
+                               f"64x64 screen tiles in column stripes of {1 << stripe} tile(s) over {N} ranks, all-to-all + one band stitched per rank + bands gathered in place"},
+       "gathered_frame_equals_single_rank_frame": equal,
+       "ranks": [{"rank": r, "hip_device": 0, "pci_bus_id": f"{di['pci_bus_id']:02x}:{di['pci_device_id']:02x}", "local_tiles": R["t"].local_tiles(),
+                  "frame_period_alone_ms": periods[r]} for r, R in enumerate(ranks)],
+       "one_gpu_frame_period_ms": one_gpu, "slowest_rank_ms": max(periods), "emulated_compute_scaling": one_gpu / max(periods),
+       "stripe_log2": stripe, "band_rows": band_rows, "chunk_tiles": chunk_tiles}
+print(json.dumps(out), flush=True)
+torch.cuda.synchronize()
+torch.cuda.set_stream(torch.cuda.default_stream(dev))
+for R in ranks:
+    R["t"].close()
+single.close()
+sys.exit(0 if equal else 3)

@@ -58,28 +58,45 @@ def make_terrain(width: int, height: int, grid: int = 128):
     return TerrainSpike(w, h, _grid(grid))
 
 
-def dem_stats(heightmap):
-    """(min, max, mean, std) of a 2-D float32/float64 C-contiguous heightmap (reference shim :120-127)."""
-    a = _np.asarray(heightmap)
-    if a.ndim != 2 or a.dtype not in (_np.float32, _np.float64) or not a.flags["C_CONTIGUOUS"]:
+def _dem_f32(heightmap):
+    """The heightmap as a float32 array, or the shim's RuntimeError: 2-D, float32 or float64, C-contiguous."""
+    dem = _np.asarray(heightmap)
+    acceptable = dem.ndim == 2 and dem.dtype.kind == "f" and dem.dtype.itemsize in (4, 8) and dem.flags.c_contiguous
+    if not acceptable:
         raise RuntimeError("heightmap must be 2-D float32/float64 and C-contiguous")
-    a = a.astype(_np.float32, copy=False)
-    return float(a.min()), float(a.max()), float(a.mean()), float(a.std(dtype=_np.float32))
+    return dem if dem.dtype == _np.float32 else dem.astype(_np.float32)
+
+
+def dem_stats(heightmap):
+    """(min, max, mean, std) of a heightmap, all taken on its float32 values; std accumulates in float32 as well
+    (python/vulkan_forge/__init__.py:120-127; pinned by tests/test_host_api.py against values captured from the reference shim)."""
+    dem = _dem_f32(heightmap)
+    return tuple(float(v) for v in (dem.min(), dem.max(), dem.mean(), dem.std(dtype=_np.float32)))
+
+
+def _rescale_minmax(dem, stats, out_range, eps):
+    lowest, highest = stats[0], stats[1]
+    lo, hi = float(out_range[0]), float(out_range[1])
+    gain = (hi - lo) / max(highest - lowest, eps) if highest != lowest else 0.0     # a flat map lands on `lo`
+    return (dem - lowest) * gain + lo
+
+
+def _rescale_zscore(dem, stats, _out_range, eps):
+    return (dem - stats[2]) / max(stats[3], eps)
+
+
+_DEM_MODES = {"minmax": _rescale_minmax, "zscore": _rescale_zscore}
 
 
 def dem_normalize(heightmap, *, mode="minmax", out_range=(0.0, 1.0), eps=1e-8, return_stats=False):
-    """minmax / zscore normalisation (reference shim :129-142)."""
-    mn, mx, mean, std = dem_stats(heightmap)
-    a = _np.asarray(heightmap).astype(_np.float32, copy=False)
-    if mode == "minmax":
-        lo, hi = (float(v) for v in out_range)
-        scale = 0.0 if mx == mn else (hi - lo) / max(mx - mn, float(eps))
-        out = (a - mn) * scale + lo
-    elif mode == "zscore":
-        out = (a - mean) / max(std, float(eps))
-    else:
+    """Heights rescaled to `out_range` ("minmax") or to zero mean / unit deviation ("zscore"), float32; with return_stats also the
+    statistics they were derived from (python/vulkan_forge/__init__.py:129-142)."""
+    stats = dem_stats(heightmap)                             # (argument errors first, like the shim)
+    rescale = _DEM_MODES.get(mode)
+    if rescale is None:
         raise ValueError("mode must be 'minmax' or 'zscore'")
-    return (out, (mn, mx, mean, std)) if return_stats else out
+    out = rescale(_dem_f32(heightmap), stats, out_range, float(eps))
+    return (out, stats) if return_stats else out
 
 
 def grid_generate(nx: int, nz: int, spacing=(1.0, 1.0), origin="center"):

@@ -8,6 +8,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <atomic>
@@ -80,6 +81,11 @@ struct vf_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     float *d_thresh = nullptr;   // 256 sRGB store thresholds
+    // Streams the handles of this context borrow, made on first need: a stream costs 3-10 ms to create and 2-3 ms to destroy on this
+    // runtime (round 5, measured), so they belong to the process-lifetime context, not to every handle.  side / side2: a frame's plan
+    // chain and set-up pass (they overlap the previous frame's tile kernel; a handle's first frame needs neither); copy: batch read-back.
+    // Handles that render at the same time share them: order is kept by events, sharing only serialises their plan chains.
+    hipStream_t side = nullptr, side2 = nullptr, copy = nullptr;
 };
 
 struct vf_terrain {
@@ -157,6 +163,8 @@ struct vf_terrain {
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint8_t *d_png = nullptr, *h_png = nullptr;   // PNG scanlines of the last frame: device, pinned host
+    uint8_t *h_png_first = nullptr;               // ... and ordinary host memory for the handle's FIRST read-back (page-locking 64 MiB costs 9 ms: more than it saves once)
+    uint32_t big_reads = 0;                       // frame-sized read-backs so far (the pinned ring / buffers are made by the second)
     uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
     hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
@@ -267,6 +275,7 @@ void vf_ctx_destroy(vf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_thresh) (void)hipFree(c->d_thresh);
+    for (hipStream_t q : { c->side, c->side2, c->copy }) if (q) (void)hipStreamDestroy(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -325,8 +334,15 @@ struct Carver {
 };
 } // namespace
 
+static hipError_t sync_sides(const vf_terrain *t)            // (the side streams exist from the handle's second frame on)
+{
+    hipError_t e = t->side ? hipStreamSynchronize(t->side) : hipSuccess;
+    if (e == hipSuccess && t->side2) e = hipStreamSynchronize(t->side2);
+    return e;
+}
+
 // A plan state's buffers and events, made when the state is first used (frame 0: at construction; frame 1: by that frame).
-static hipError_t ensure_plan_state(vf_terrain *t, uint32_t k)
+static hipError_t ensure_plan_state(vf_terrain *t, uint32_t k, hipStream_t zero_on)
 {
     vf_terrain::PlanState &S = t->ps[k];
     if (S.slab) return hipSuccess;
@@ -348,7 +364,7 @@ static hipError_t ensure_plan_state(vf_terrain *t, uint32_t k)
     C.add((void **)&S.work_count, 4 * sizeof(uint32_t));
     C.add((void **)&S.redo, (all_tiles + kSplitBudget) * sizeof(uint32_t));
     C.add((void **)&S.flags_new, all_tiles * sizeof(uint32_t));
-    hipError_t err = C.commit(&S.slab, t->side);          // (the state's first user is the plan chain on `side`)
+    hipError_t err = C.commit(&S.slab, zero_on);          // (the stream of the state's first user: the plan chain)
     if (err != hipSuccess) { S.slab = nullptr; return err; }
     S.work_sorted = S.work + (all_tiles + kSplitBudget + 16);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&S.planned, hipEventDisableTiming);
@@ -416,11 +432,11 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     C.add((void **)&t->d_rgba_own, all_tiles * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     C.add((void **)&t->d_tile_map, all_tiles * sizeof(uint32_t));
     err = C.commit(&t->slab, ctx->stream);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&t->side2, hipStreamNonBlocking);
+    // (the two side streams are made by the handle's SECOND frame: a stream costs ~2 ms to create and as much to destroy, and a
+    //  handle's first frame -- the only one of the reference's construct / render_png once usage -- has nothing to overlap with)
     if (err == hipSuccess) err = hipMemcpyAsync(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, ctx->stream);   // (pageable source: returns when the copy is staged)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
-    if (err == hipSuccess) err = ensure_plan_state(t, 0);
+    if (err == hipSuccess) err = ensure_plan_state(t, 0, ctx->stream);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -444,7 +460,7 @@ void vf_terrain_destroy(vf_terrain *t)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : t->batch_drawn) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->batch_copied) if (e) (void)hipEventDestroy(e);
-    if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
+
     for (auto &S : t->ps) {
         if (S.slab) (void)hipFree(S.slab);
         if (S.planned) (void)hipEventDestroy(S.planned);
@@ -452,12 +468,12 @@ void vf_terrain_destroy(vf_terrain *t)
         if (S.boxed) (void)hipEventDestroy(S.boxed);
         if (S.set_up) (void)hipEventDestroy(S.set_up);
     }
-    if (t->side) (void)hipStreamDestroy(t->side);
-    if (t->side2) (void)hipStreamDestroy(t->side2);
+    // (side / side2 / copy_stream belong to the context)
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
     if (t->d_png) (void)hipFree(t->d_png);
     if (t->h_png) (void)hipHostFree(t->h_png);
+    if (t->h_png_first) std::free(t->h_png_first);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
     for (auto &g : t->gprobe) { if (g.b) (void)hipEventDestroy(g.b); }
@@ -488,7 +504,7 @@ int vf_terrain_set_height(vf_terrain *t, const float *host_height, uint32_t tw, 
     if (tw == 0 || th == 0 || tw > 32768 || th > 32768) return fail(VF_ERR_INVALID, "height texture size must be in 1..32768");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
-    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
+    VF_HIP_TRY(sync_sides(t));
     size_t bytes = (size_t)tw * th * sizeof(float);
     if ((size_t)t->tw * t->th != (size_t)tw * th || t->d_height != t->d_height_own) {
         float *fresh = nullptr;                            // allocate first: a failure leaves the handle as it was
@@ -520,7 +536,7 @@ int vf_terrain_set_height_device(vf_terrain *t, const float *dev_height, uint32_
     // a frame still in flight (caller's stream, or the plan / height-cache kernels on the side stream) reads the axis tables
     // and the old texture: let it finish before either changes
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
-    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
+    VF_HIP_TRY(sync_sides(t));
     t->d_height = dev_height;
     int rc = set_height_common(t, tw, th);
     if (rc != VF_OK) return rc;
@@ -575,7 +591,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     t->rendered = false; t->have_frame = false;
     t->frames_since_reset = 0;
     // tile numbering changed: forget the scheduling feedback of the previous layout
-    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
+    VF_HIP_TRY(sync_sides(t));
     for (auto &S : t->ps) {
         if (!S.slab) continue;                             // (a state not used yet starts at zero when it is made)
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
@@ -621,7 +637,7 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
     t->rendered = false; t->have_frame = false;
     t->frames_since_reset = 0;
-    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
+    VF_HIP_TRY(sync_sides(t));
     for (auto &S : t->ps) {
         if (!S.slab) continue;                             // (a state not used yet starts at zero when it is made)
         VF_HIP_TRY(hipMemset(S.feedback, 0, ((size_t)t->ntx * t->nty * 65 + 1) * sizeof(uint32_t)));
@@ -786,7 +802,17 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const uint32_t set = t->cur_set;
     t->cur_set = (set + 1u) % vf_terrain::kPlanStates;
     t->frame_no++;
-    VF_HIP_TRY(ensure_plan_state(t, set));                                 // (a handle's second frame makes the second state)
+    // A handle's FIRST frame runs on the caller's stream alone, plan and set-up included: its chain is serial anyway (the static plan
+    // estimate reads the set-up pass's records) and there is no earlier frame to hide anything under.  The side streams and the second
+    // plan state are made by the second frame.
+    const bool solo = !t->side && t->frame_no == 1u;
+    if (!solo && !t->side) {
+        vf_ctx *c = t->ctx;                                  // (borrowed from the context: made once per process)
+        if (!c->side) VF_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        if (!c->side2) VF_HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+        t->side = c->side; t->side2 = c->side2;
+    }
+    VF_HIP_TRY(ensure_plan_state(t, set, solo ? s : t->side));
     vf_terrain::PlanState &S = t->ps[set], &O = t->ps[t->last_set];       // this frame's plan state, the previous frame's
     // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
     // a camera that moves the picture by a good part of a tile per frame waits for the previous frame instead and uses ITS feedback:
@@ -826,7 +852,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     const bool dilate = fresh || shift > 0.5f * kFreshFeedbackPx;     // slower motion: still overlapped, but the tile weights spread to the neighbours
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
-    hipStream_t side = t->side;
+    hipStream_t side = solo ? s : t->side, side2 = solo ? s : t->side2;
     hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
     // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
     VF_HIP_TRY(hipStreamWaitEvent(side, S.drawn, 0));
@@ -851,7 +877,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // vertex stage + tile-independent culling, once per frame (streams ~1.3 KB per block into this frame's plan state): needs the
     // block boxes only, so it runs on a second stream beside k_plan / k_plan_sort -- all of them under the previous frame's tile kernel
     VF_HIP_TRY(hipEventRecord(S.boxed, side));
-    VF_HIP_TRY(hipStreamWaitEvent(t->side2, S.boxed, 0));               // (orders it after S.drawn and the height cache too)
+    VF_HIP_TRY(hipStreamWaitEvent(side2, S.boxed, 0));                  // (orders it after S.drawn and the height cache too)
     // (one short-lived workgroup per possible segment -- those beyond the list's length leave at once: workgroups that come and go
     //  share the CUs with the previous frame's tile kernel more smoothly than a few long-lived ones)
     // (experiments only, VF_DBG_NO_SETUP=1: a camera at rest re-creates the same records in the same buffers, so after the first frames
@@ -862,9 +888,9 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     constexpr bool dbg_no_setup = false;
 #endif
     if (!(dbg_no_setup && t->frames_since_reset > 6))
-    hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, t->side2,
+    hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, side2,
                        P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen, S.seg_list, seg_count);
-    VF_HIP_TRY(hipEventRecord(S.set_up, t->side2));
+    VF_HIP_TRY(hipEventRecord(S.set_up, side2));
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
         if (fresh) {
@@ -1032,7 +1058,8 @@ int vf_terrain_render_batch_host(vf_terrain *t, const float *uniforms, uint32_t 
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     constexpr uint32_t R = vf_terrain::kBatchRing;
     const size_t frame_bytes = (size_t)t->W * t->H * 4, slot_bytes = (size_t)t->ntx * t->nty * kTileW * kTileH * 4;
-    if (!t->copy_stream) VF_HIP_TRY(hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking));
+    if (!t->ctx->copy) VF_HIP_TRY(hipStreamCreateWithFlags(&t->ctx->copy, hipStreamNonBlocking));
+    t->copy_stream = t->ctx->copy;
     for (uint32_t r = 0; r < R && r < n; ++r) {
         if (!t->d_batch[r]) VF_HIP_TRY(hipMalloc(&t->d_batch[r], slot_bytes));
         if (!t->batch_drawn[r]) VF_HIP_TRY(hipEventCreateWithFlags(&t->batch_drawn[r], hipEventDisableTiming));
@@ -1077,7 +1104,7 @@ static int render_visibility(vf_terrain *t)
     if (!t->d_rgba_scratch) VF_HIP_TRY(hipMalloc(&t->d_rgba_scratch, npx * sizeof(uint32_t)));
     int rc = vf_terrain_sync(t);
     if (rc != VF_OK) return rc;
-    VF_HIP_TRY(hipStreamSynchronize(t->side)); VF_HIP_TRY(hipStreamSynchronize(t->side2));
+    VF_HIP_TRY(sync_sides(t));
     float u_now[44], u_drawn[32];
     std::memcpy(u_now, t->u, sizeof u_now); std::memcpy(u_drawn, t->u_drawn, sizeof u_drawn);
     uint32_t *const out_now = t->d_rgba;
@@ -1128,7 +1155,9 @@ static bool is_pinned_host(const void *p)
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
     // a destination in pinned host memory (vf_host_alloc, or the caller's own hipHostMalloc / hipHostRegister): one DMA, nothing to stage
-    if (n < kStageChunk || is_pinned_host(dst)) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
+    // ... and a handle's FIRST frame-sized read-back goes through the runtime's own staging (5 ms for 64 MiB): the ring below costs 4 ms to
+    // page-lock and pays off from the second read on -- the reference's usage is construct, render once (src/terrain/mod.rs:410-491)
+    if (n < kStageChunk || is_pinned_host(dst) || (!t->h_stage && t->big_reads++ == 0)) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
     if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, kStageSlots * kStageChunk, hipHostMallocDefault));
     for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
@@ -1203,13 +1232,24 @@ int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines,
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     const size_t n = ((size_t)t->W * 4 + 1) * t->H;
     if (!t->d_png) VF_HIP_TRY(hipMalloc(&t->d_png, n));
-    if (!t->h_png) VF_HIP_TRY(hipHostMalloc(&t->h_png, n, hipHostMallocDefault));     // persistent: the reference allocates per call (:446-451)
     hipStream_t s = t->last_stream ? t->last_stream : t->ctx->stream;
     hipLaunchKernelGGL(k_png_filter, dim3(t->H), dim3(256), 0, s, (const uint32_t *)t->d_rgba, t->W, t->d_png);
     VF_HIP_TRY(hipGetLastError());
-    VF_HIP_TRY(hipMemcpyAsync(t->h_png, t->d_png, n, hipMemcpyDeviceToHost, s));
+    // the handle's first read-back lands in ordinary memory (the runtime stages it); the page-locked buffer -- 9 ms to make for a C4
+    // frame, then one DMA per frame -- is made by the second: persistent, where the reference allocates per call (:446-451)
+    uint8_t *host = nullptr;
+    if (!t->h_png && t->big_reads++ == 0 && n >= kStageChunk) {
+        if (!t->h_png_first) t->h_png_first = (uint8_t *)std::malloc(n);
+        if (!t->h_png_first) return fail(VF_ERR_NOMEM, "out of host memory");
+        host = t->h_png_first;
+    } else {
+        if (!t->h_png) VF_HIP_TRY(hipHostMalloc(&t->h_png, n, hipHostMallocDefault));
+        if (t->h_png_first) { std::free(t->h_png_first); t->h_png_first = nullptr; }
+        host = t->h_png;
+    }
+    VF_HIP_TRY(hipMemcpyAsync(host, t->d_png, n, hipMemcpyDeviceToHost, s));
     VF_HIP_TRY(hipStreamSynchronize(s));
-    *host_scanlines = t->h_png;
+    *host_scanlines = host;
     *nbytes = n;
     return VF_OK;
 }

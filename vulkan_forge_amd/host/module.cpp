@@ -263,7 +263,9 @@ public:
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
         const size_t bytes = (size_t)rows * W * 4;
-        if (bytes < ((size_t)4 << 20) || std::getenv("VF_RGBA_PAGEABLE")) {     // small frames: an ordinary array, one direct copy
+        // small frames, and an object's FIRST frame (page-locking a C4 frame costs 9 ms, more than it saves once: the reference's usage is
+        // construct, render once): an ordinary array
+        if (bytes < ((size_t)4 << 20) || rgba_calls++ == 0 || std::getenv("VF_RGBA_PAGEABLE")) {
             py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
             render_into(a.mutable_data(), rows);
             return a;
@@ -377,6 +379,7 @@ private:
         check(vf_terrain_set_uniforms(t, last.data()));
     }
     uint32_t W, H, n = 128;
+    uint32_t rgba_calls = 0;
     vf_terrain *t = nullptr;
     Globals globals;
     Mat4 view{}, proj{};
