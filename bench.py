@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SETTLE = 16                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, the handle probes its two line loops (frames 4..15)
+SETTLE = 24                     # untimed frames of a new camera before the warm-up (see timed()): the plan's feedback settles, the handle probes its two line loops (frames 4..19)
 
 
 def parse():
@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--stripe-log2", type=int, default=None,
                     help="N>1: log2 of the width, in tiles, of the column stripes dealt to the ranks (default: a period of eight tile columns -- "
                          "4 tiles for 2 ranks, 2 for 4, 1 from 8 on; vulkan_forge_amd/dist.py::default_stripe_log2)")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N>1: keep the round-robin deal of the column stripes (default: after the settle frames the stripes are dealt again by "
+                         "their measured times -- vf_terrain_tile_times, summed over the ranks, vf_balance_stripes -- and the plan settles once more)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dress rehearsal on ONE GPU: every rank uses device 0 and the exchange runs over gloo through host "
                          "memory (RCCL refuses two ranks on one device); exercises sharding, exchange and reporting, not xGMI")
@@ -320,6 +323,7 @@ def main():
         ex.pending_frame = [False] * depth
 
     exchanged = [False]
+    balance_info = {}
     # SETTLE untimed frames are set-up, not steps: the frame plan is feedback-driven (a frame's per-tile times decide order and
     # strip splitting two frames later, because frames overlap) and needs a few frames of a new camera to converge; results
     # never depend on it.  The JSON reports `settle_frames` and what a frame without feedback costs (`cold_frame_ms`).
@@ -333,6 +337,24 @@ def main():
             for _ in range(SETTLE):                                  # the orbit itself: settle on the poses before the first timed one
                 step()
             pose[0] = rank
+        if ex is not None and banded and not args.no_balance and not c5:
+            # set-up, not steps: the stripes dealt again by what they cost under THIS camera.  Every rank knows the times of its own tiles;
+            # summed per stripe and all-reduced they are the same vector on every rank, and the deterministic rule gives every rank the
+            # same table.  Every rank keeps its number of stripes: slabs, chunks and bands keep their sizes.
+            sl2 = vdist.layout_stripe_log2(ex.skew)
+            nstripes = ((W + 63) // 64) >> sl2
+            mine = vdist.stripe_times(t.tile_times(), vdist.tile_layout(W, H, rank, world, ex.skew), nstripes, sl2)
+            x = torch.from_numpy(mine).to("cpu" if args.rehearse else dev)
+            dist.all_reduce(x, op=dist.ReduceOp.SUM)
+            word = vdist.balanced_layout(x.cpu().numpy(), world, sl2)
+            balance_info.update({"stripe_ms": [round(float(v), 4) for v in x.cpu().numpy()], "camera": camera,
+                                 "owner": [int(o) for o in cabi.balance_stripes(x.cpu().numpy(), world)]})
+            if word != ex.skew:
+                flush()
+                ex.set_layout(word)
+                t.set_tile_shard(rank, world, word)
+                for _ in range(SETTLE):
+                    t.render(stream)
         if ex is not None and not exchanged[0]:
             # set-up, not steps: the first exchange creates the point-to-point channels (RCCL opens them lazily, about a second);
             # like communicator creation it must not land in the timed region when the caller asks for --warmup 0
@@ -598,7 +620,9 @@ def main():
             metric = "Mpix/s terrain shade (grid=4096, 4096x4096)" if (W, G) == (4096, 4096) else f"Mpix/s terrain shade (grid={G}, {W}x{H})"
             workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
             par = ("1 GPU, whole frame" if world == 1 else
-                   f"64x64 screen tiles in column stripes of {1 << (ex.skew >> 16)} tile(s) interleaved over {world} GPUs (owner = ((tx >> {ex.skew >> 16}) + {ex.skew & 0xFFFF}*ty) % {world}), " +
+                   f"64x64 screen tiles in column stripes of {1 << vdist.layout_stripe_log2(ex.skew)} tile(s) over {world} GPUs (" +
+                   ("stripes dealt by their measured times, the same number to every rank: vf_balance_stripes" if balance_info else
+                    f"owner = ((tx >> {vdist.layout_stripe_log2(ex.skew)}) + {ex.skew & 0xFFFF}*ty) % {world}") + "), " +
                    ("all-to-all (RCCL through the C-ABI, vf_dist_exchange_bands) + one band stitched per rank + bands gathered in place on rank 0, " if cabi_bands else
                     "all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
                     f"p2p gather to rank 0 ({'RCCL through the C-ABI, vf_dist_gather_tiles' if comm is not None else 'RCCL via torch.distributed'}) + stitch, ") +
@@ -628,6 +652,8 @@ def main():
             out["cold_frames_ms"] = {"first (planned from the static estimate: no feedback yet)": cold[0], "second (first frame's feedback)": cold[1], "third": cold[2]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
+        if balance_info:
+            out["stripe_balance"] = balance_info
         if ranks_info is not None:
             out["ranks"] = ranks_info
             out["rccl"] = rccl

@@ -157,6 +157,22 @@ int vf_terrain_local_rows(const vf_terrain *t, uint32_t *rows);
  * vf_stitch_tiles_device. */
 #define VF_TILE_LAYOUT(skew, stripe_log2) ((uint32_t)(skew) | ((uint32_t)(stripe_log2) << 16))
 int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t layout);
+/* Load-balanced stripes (round 5; SURVEY.md 8(e) "a load-balanced map").  The round-robin deal gives every rank the same NUMBER of
+ * stripes, not the same work: at C4's top-down camera the slowest of 4 ranks carries 15 % more than the fastest.  Three pieces:
+ *   vf_terrain_tile_times      the time (ms) the handle's last frame spent on each of its local tiles (what its own frame plan
+ *                              feeds on); summed per stripe and added up over the ranks by the host (an all-reduce of <= 256 floats)
+ *                              they are the per-stripe cost every rank agrees on.  *count = local tiles; ms may be NULL to count.
+ *   vf_balance_stripes         the deterministic rule: heaviest stripe first, each to the least loaded rank that still has room --
+ *                              every rank keeps nstripes / nranks stripes, so slabs and exchanged chunks keep their sizes; the same
+ *                              times give the same table on every rank.
+ *   vf_tile_layout_register_map  an owner table (owner[sc] for the stripe sc = tx >> stripe_log2) -> a layout WORD (bit 20 set) that
+ *                              every entry point taking a layout accepts: vf_terrain_set_tile_shard, vf_tile_layout,
+ *                              vf_stitch_tiles_device, and through the handle vf_dist_exchange_bands / vf_dist_gather_tiles.  Tables
+ *                              are immutable and process-wide (64 at most); registering the same table again returns the same word.
+ * No reference counterpart (single device: src/terrain/mod.rs:277-294). */
+int vf_terrain_tile_times(vf_terrain *t, float *ms, uint32_t capacity, uint32_t *count);
+int vf_balance_stripes(const float *stripe_ms, uint32_t nstripes, uint32_t nranks, uint8_t *stripe_owner);
+int vf_tile_layout_register_map(const uint8_t *stripe_owner, uint32_t nstripes, uint32_t stripe_log2, uint32_t nranks, uint32_t *layout);
 int vf_terrain_local_tiles(const vf_terrain *t, uint32_t *tiles);
 int vf_terrain_read_tiles(vf_terrain *t, uint8_t *dst, uint32_t first, uint32_t count);
 int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nranks, uint32_t layout, uint32_t *tiles,

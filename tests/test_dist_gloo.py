@@ -159,7 +159,7 @@ def test_tile_layout_properties():
 
 
 # ---- tile shards stitched in parallel: all-to-all + one band per rank + in-place band gather (dist.BandStitchExchange) ----------
-def _band_worker(rank, world, port, W, H, G, q, stripe=0):
+def _band_worker(rank, world, port, W, H, G, q, stripe=0, owner=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -174,6 +174,10 @@ def _band_worker(rank, world, port, W, H, G, q, stripe=0):
     assert vdist.band_exchange_applies(W, H, world, stripe)
     ex = vdist.BandStitchExchange(W, H, "cpu", depth=2, stripe_log2=stripe)
     assert ex.skew == vdist.layout_code(0, stripe)
+    if owner is not None:                                               # a load-balanced deal of the same stripes (registered stripe map)
+        from vulkan_forge_amd import cabi
+        ex.set_layout(cabi.register_stripe_map(owner, stripe, world))
+        assert ex.skew & (1 << 20) and vdist.layout_stripe_log2(ex.skew) == stripe
     lay = vdist.tile_layout(W, H, rank, world, ex.skew)
     assert len(lay) == ex.stride
 
@@ -203,13 +207,14 @@ def _band_worker(rank, world, port, W, H, G, q, stripe=0):
 
 
 # (8, 512, 512, 0): the layout of the driver's 8-GPU run in small -- single-column stripes, eight bands of whole tile rows, 64-tile frame
-@pytest.mark.parametrize("world,W,H,stripe", [(2, 256, 128, 0), (4, 256, 256, 0), (2, 512, 128, 2), (4, 512, 256, 1), (8, 512, 512, 0)])
-def test_tile_shards_band_stitch_exchange(world, W, H, stripe):
+@pytest.mark.parametrize("world,W,H,stripe,owner", [(2, 256, 128, 0, None), (4, 256, 256, 0, None), (2, 512, 128, 2, None), (4, 512, 256, 1, None), (8, 512, 512, 0, None),
+                                                     (4, 512, 256, 0, [3, 0, 1, 2, 2, 1, 0, 3]), (2, 512, 128, 1, [1, 0, 0, 1])])
+def test_tile_shards_band_stitch_exchange(world, W, H, stripe, owner):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, 32, q, stripe)) for r in range(world)]
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, 32, q, stripe, owner)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -223,3 +228,43 @@ def test_band_exchange_applicability():
     assert vdist.band_exchange_applies(4096, 4096, 8) and vdist.band_exchange_applies(4096, 4096, 2) and vdist.band_exchange_applies(4096, 4096, 4)
     assert not vdist.band_exchange_applies(1920, 1080, 8) and not vdist.band_exchange_applies(4096, 4096, 3) and not vdist.band_exchange_applies(200, 150, 2)
     assert vdist.band_exchange_applies(4096, 4096, 2, 2) and vdist.band_exchange_applies(4096, 4096, 4, 1) and not vdist.band_exchange_applies(256, 256, 2, 2)
+
+
+def test_balanced_stripe_maps():
+    """vf_balance_stripes + vf_tile_layout_register_map (host arithmetic): every rank keeps its number of stripes, the deal is a function
+    of the times alone, a map's layout word partitions the frame like any other layout and keeps the storage order."""
+    from vulkan_forge_amd import cabi, dist as vdist
+    rng = np.random.default_rng(11)
+    for nstripes, n in ((64, 8), (32, 4), (16, 2), (64, 2), (8, 8)):
+        ms = rng.random(nstripes).astype(np.float32) ** 3
+        owner = cabi.balance_stripes(ms, n)
+        assert np.array_equal(owner, cabi.balance_stripes(ms.copy(), n))
+        assert np.bincount(owner, minlength=n).tolist() == [nstripes // n] * n
+        loads = np.bincount(owner, weights=ms, minlength=n)
+        naive = np.bincount(np.arange(nstripes) % n, weights=ms, minlength=n)
+        assert loads.max() <= naive.max() + 1e-6
+    with pytest.raises(cabi.VfError):
+        cabi.balance_stripes(np.ones(10, np.float32), 4)                  # must divide evenly
+    assert cabi.balance_stripes(np.array([np.nan, 1, 2, np.inf], np.float32), 2).tolist() in ([0, 1, 0, 1], [1, 1, 0, 0], [1, 0, 0, 1], [0, 0, 1, 1], [1, 0, 1, 0], [0, 1, 1, 0])
+    owner = np.array([3, 0, 1, 2, 2, 1, 0, 3], np.uint8)
+    word = cabi.register_stripe_map(owner, 1, 4)
+    assert word == cabi.register_stripe_map(owner.copy(), 1, 4) and word & (1 << 20) and vdist.layout_stripe_log2(word) == 1
+    W, H = 1024, 200                                                     # 16 tile columns = 8 stripes of 2
+    seen = np.full((4, 16), -1)
+    for r in range(4):
+        lay = vdist.tile_layout(W, H, r, 4, word)
+        assert len(lay) == 4 * 4 and [tuple(x) for x in lay] == sorted((tuple(x) for x in lay), key=lambda p: (p[1], p[0]))
+        for tx, ty in lay:
+            assert owner[tx >> 1] == r and seen[ty, tx] == -1
+            seen[ty, tx] = r
+    assert (seen >= 0).all()
+    with pytest.raises(cabi.VfError):
+        vdist.tile_layout(W, H, 0, 2, word)                               # made for four ranks
+    with pytest.raises(cabi.VfError):
+        vdist.tile_layout(4096, H, 0, 4, word)                            # a wider frame has stripes the table does not name
+    with pytest.raises(cabi.VfError):
+        cabi.register_stripe_map([0, 5], 0, 2)
+    with pytest.raises(cabi.VfError):
+        vdist.tile_layout(W, H, 0, 4, (1 << 20) | (63 << 21))            # no such map
+    st = vdist.stripe_times(np.arange(8, dtype=np.float32), [(0, 0), (1, 0), (4, 0), (5, 0), (0, 1), (1, 1), (4, 1), (5, 1)], 4, 1)
+    assert st.tolist() == [0 + 1 + 4 + 5, 0.0, 2 + 3 + 6 + 7, 0.0]

@@ -264,7 +264,19 @@ def test_c4_full_size_properties(c4, oracle, cam):
     # interleaved-tile shards (the bench's N > 1 layout): every rank's tile-major slab, placed by vf_tile_layout
     from vulkan_forge_amd import cabi as _cabi
     # skew 0 (column stripes) is the bench's N > 1 layout: single tile columns for 8 ranks, stripes of 2 tiles for 4, of 4 tiles for 2
-    for nranks, skew in ((2, 1), (8, 3), (3, 5), (2, 0), (4, 0), (8, 0), (2, 2 << 16), (4, 1 << 16), (3, (1 << 16) | 2)):
+    # ... and load-balanced deals of the same stripes (round 5): the stripes' measured times -> vf_balance_stripes -> a registered map
+    t.set_shard(0, 1, 64); t.render()
+    col_ms = t.tile_times().reshape(H // 64, W // 64).sum(axis=0)
+    maps = []
+    for nranks, sl2 in ((2, 2), (4, 1), (8, 0)):
+        stripe_ms = col_ms.reshape(-1, 1 << sl2).sum(axis=1)
+        owner = _cabi.balance_stripes(stripe_ms, nranks, lib=t.lib)
+        assert np.bincount(owner, minlength=nranks).tolist() == [len(owner) // nranks] * nranks
+        loads = np.bincount(owner, weights=stripe_ms, minlength=nranks)
+        naive = np.bincount(np.arange(len(owner)) % nranks, weights=stripe_ms, minlength=nranks)
+        assert loads.max() <= naive.max() * 1.0001, (nranks, loads, naive)       # never worse than the round-robin deal on measured times
+        maps.append((nranks, _cabi.register_stripe_map(owner, sl2, nranks, lib=t.lib)))
+    for nranks, skew in [(2, 1), (8, 3), (3, 5), (2, 0), (4, 0), (8, 0), (2, 2 << 16), (4, 1 << 16), (3, (1 << 16) | 2)] + maps:
         out = np.zeros_like(a)
         for r in range(nranks):
             t.set_tile_shard(r, nranks, skew)
@@ -611,7 +623,9 @@ def test_fast_precision_shards_equal_the_whole_frame(cabi, oracle, luts, seed):
                     t.render()
                 out[np.flatnonzero(((np.arange(H) // band) % n) == r)] = t.read_rgba()
             assert np.array_equal(out, whole), (n, band)
-        for n, skew in ((2, 0), (4, 0), (8, 0), (3, 5), (2, 2 << 16), (4, 1 << 16)):
+        ncols = (W + 63) // 64
+        balanced2 = cabi.register_stripe_map(cabi.balance_stripes(rng.random(ncols // 2 * 2), 2)[:ncols // 2 * 2].tolist() + [0] * (ncols % 2), 0, 2)
+        for n, skew in ((2, 0), (4, 0), (8, 0), (3, 5), (2, 2 << 16), (4, 1 << 16), (2, balanced2)):
             out = np.zeros_like(whole)
             for r in range(n):
                 t.set_tile_shard(r, n, skew)
@@ -661,7 +675,8 @@ t.close()
 W, H, G = 200, 150, 48
 u = oracle.default_uniforms(1, W, H)
 ref, _ = oracle.render_terrain(u, W, H, G, h, lut)
-for nr, skew in ((3, 5), (2, 1), (5, 3), (2, 1 << 16), (3, (1 << 16) | 1), (2, 2 << 16)):     # (the last ones: stripes of 2 / 4 tiles -- the layout word skew | stripe_log2 << 16)
+maps = [(2, cabi.register_stripe_map([1, 0, 0, 1], 0, 2)), (3, cabi.register_stripe_map([2, 0, 1, 1], 0, 3)), (2, cabi.register_stripe_map([1, 0], 1, 2))]   # registered stripe maps (owner per column stripe; 200 px = 4 tile columns)
+for nr, skew in [(3, 5), (2, 1), (5, 3), (2, 1 << 16), (3, (1 << 16) | 1), (2, 2 << 16)] + maps:     # (stripes of 2 / 4 tiles: the layout word skew | stripe_log2 << 16)
     t = cabi.Terrain(W, H, G, lut)
     t.set_uniforms(u); t.set_height_device(d_h.data_ptr(), 64, 64); t.set_shade_precision(0)
     stride = max(len(cabi.tile_layout(W, H, r, nr, skew, lib=t.lib)) for r in range(nr)) + 1     # a stride larger than needed is fine

@@ -3,6 +3,7 @@ VF_HIP_LIB selects the library (tools/build_variant.sh); with a -DVF_EXPERIMENTS
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("VF_IMPORT_TORCH"): import torch
 import vulkan_forge_amd as vf
 from vulkan_forge_amd import cabi
 import importlib.util

@@ -19,7 +19,7 @@ SYMBOLS = [
     "vf_last_error", "vf_device_count", "vf_device_query", "vf_ctx_create", "vf_ctx_destroy", "vf_ctx_device_info", "vf_ctx_stream",
     "vf_terrain_create", "vf_terrain_destroy", "vf_terrain_set_uniforms", "vf_terrain_set_height",
     "vf_terrain_set_height_device", "vf_terrain_set_shade_mode", "vf_terrain_set_shade_precision", "vf_terrain_set_raster_groups", "vf_terrain_raster_groups", "vf_terrain_set_shard", "vf_terrain_local_rows", "vf_terrain_set_tile_shard",
-    "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_set_output_device",
+    "vf_terrain_local_tiles", "vf_terrain_read_tiles", "vf_tile_layout", "vf_terrain_tile_times", "vf_balance_stripes", "vf_tile_layout_register_map", "vf_terrain_set_output_device",
     "vf_terrain_rgba_device", "vf_terrain_render", "vf_terrain_render_batch", "vf_terrain_render_batch_host", "vf_terrain_sync", "vf_terrain_read_rgba", "vf_terrain_read_png_scanlines", "vf_terrain_read_visibility",
     "vf_terrain_enable_timing", "vf_terrain_timings", "vf_terrain_frame_times", "vf_terrain_debug_item_stats", "vf_terrain_debug_phase_cycles", "vf_grid_generate", "vf_grid_generate_device", "vf_triangle_render",
     "vf_stitch_bands_device", "vf_stitch_tiles_device",
@@ -84,6 +84,9 @@ _PROTOS = {
     "vf_terrain_frame_times": (_i, [_vp, _vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_item_stats": (_i, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "vf_terrain_debug_phase_cycles": (_i, [_vp, _vp, _u32]),
+    "vf_terrain_tile_times": (_i, [_vp, _vp, _u32, C.POINTER(_u32)]),
+    "vf_balance_stripes": (_i, [_vp, _u32, _u32, _vp]),
+    "vf_tile_layout_register_map": (_i, [_vp, _u32, _u32, _u32, C.POINTER(_u32)]),
     "vf_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
     "vf_host_free": (None, [_vp]),
     "vf_grid_generate": (_i, [_vp, _u32, _u32, _f, _f, _vp, _vp, _vp]),
@@ -137,6 +140,26 @@ def tile_layout(width, height, rank, nranks, skew=3, lib=None):
         raise VfError(lib.vf_last_error().decode())
     packed = packed[:n.value]
     return np.stack([packed & 0xFFFF, packed >> 16], axis=1).astype(np.int64)
+
+
+def balance_stripes(stripe_ms, nranks, lib=None):
+    """vf_balance_stripes: per-stripe times -> owner per stripe (uint8), every rank with the same number of stripes."""
+    lib = lib or load()
+    ms = np.ascontiguousarray(stripe_ms, np.float32)
+    owner = np.zeros(len(ms), np.uint8)
+    if lib.vf_balance_stripes(ms.ctypes.data, len(ms), nranks, owner.ctypes.data) != VF_OK:
+        raise VfError(lib.vf_last_error().decode())
+    return owner
+
+
+def register_stripe_map(stripe_owner, stripe_log2, nranks, lib=None):
+    """vf_tile_layout_register_map: owner table -> layout word accepted wherever a layout is (set_tile_shard, tile_layout, stitch_tiles)."""
+    lib = lib or load()
+    owner = np.ascontiguousarray(stripe_owner, np.uint8)
+    word = _u32()
+    if lib.vf_tile_layout_register_map(owner.ctypes.data, len(owner), stripe_log2, nranks, C.byref(word)) != VF_OK:
+        raise VfError(lib.vf_last_error().decode())
+    return word.value
 
 
 class Terrain:
@@ -218,6 +241,14 @@ class Terrain:
     def set_tile_shard(self, rank, nranks, skew=3):
         """`skew`: the layout word skew | stripe_log2 << 16 (include/vf_hip.h, VF_TILE_LAYOUT)."""
         self._check(self.lib.vf_terrain_set_tile_shard(self.t, rank, nranks, skew))
+
+    def tile_times(self):
+        """ms the last frame spent on each local tile (storage order: vf_tile_layout's)."""
+        n = _u32()
+        self._check(self.lib.vf_terrain_tile_times(self.t, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        self._check(self.lib.vf_terrain_tile_times(self.t, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def local_tiles(self):
         n = _u32()

@@ -73,6 +73,7 @@ struct FrameParams {
     uint32_t skew;                  // shard_tiles: tile (tx, ty) belongs to rank ((tx >> stripe_shift) + skew * ty) % nranks
     uint32_t stripe_shift;          // log2 of the stripe width in tiles (0: single tile columns)
     const uint32_t *tile_map;       // shard_tiles: local tile -> tx | ty << 16
+    const uint8_t *stripe_owner;    // shard_tiles with a registered stripe map (vf_tile_layout_register_map): owner per column stripe; else NULL
     uint32_t clear_rgba;            // packed sRGB8 clear colour
     uint32_t shade_mode;            // 0 REFERENCE (terrain.wgsl as coded), 1 SPEC_T32 (the documented fragment stage)
     const float *tex;               // height texture (SPEC_T32 normals)

@@ -13,6 +13,7 @@
 #include <string>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types only: the functions are resolved at run time (resolve_rccl)
@@ -66,7 +67,34 @@ bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 // to rank ((tx >> stripe_log2) + skew * ty) % nranks.
 uint32_t layout_skew(uint32_t layout) { return layout & 0xFFFFu; }
 uint32_t layout_shift(uint32_t layout) { return (layout >> 16) & 0xFu; }
-bool layout_valid(uint32_t layout) { return (layout >> 20) == 0u; }      // skew < 65536, stripe_log2 <= 15, nothing above
+// Round 5: a layout word with bit 20 set names a REGISTERED stripe map (vf_tile_layout_register_map): an explicit owner per column
+// stripe instead of the round-robin rule -- what a load-balanced deal of the stripes needs (vf_balance_stripes).  Bits 21..26: the
+// map's number in the process-wide registry below; skew 0 by construction (column stripes).  Maps are immutable once registered.
+constexpr uint32_t kLayoutMapBit = 1u << 20, kMaxStripeMaps = 64, kMaxStripes = 256;
+struct StripeMap { std::vector<uint8_t> owner; uint32_t shift = 0, nranks = 0; };
+std::mutex g_maps_mu;
+std::vector<StripeMap> g_maps;                              // (entries are never removed or changed: a pointer into it stays valid ... while the vector does not grow:
+const StripeMap *layout_map(uint32_t layout)                //  so it is reserved to its final capacity at the first registration)
+{
+    if (!(layout & kLayoutMapBit)) return nullptr;
+    std::lock_guard<std::mutex> lk(g_maps_mu);
+    const uint32_t id = (layout >> 21) & 0x3Fu;
+    return id < g_maps.size() ? &g_maps[id] : nullptr;
+}
+bool layout_valid(uint32_t layout)
+{
+    if (layout & kLayoutMapBit) {
+        const StripeMap *m = layout_map(layout);
+        return m && (layout >> 27) == 0u && layout_skew(layout) == 0u && layout_shift(layout) == m->shift;
+    }
+    return (layout >> 20) == 0u;                            // skew < 65536, stripe_log2 <= 15, nothing above
+}
+// owner of tile (tx, ty) under a layout word (valid, see above)
+uint32_t layout_owner(uint32_t layout, const StripeMap *m, uint32_t tx, uint32_t ty, uint32_t nranks)
+{
+    if (m) { const uint32_t sc = tx >> m->shift; return sc < m->owner.size() ? m->owner[sc] : 0u; }
+    return ((tx >> layout_shift(layout)) + layout_skew(layout) * ty) % nranks;
+}
 uint32_t ilog2(uint32_t v)
 {
     uint32_t s = 0;
@@ -86,6 +114,8 @@ struct vf_ctx {
     // chain and set-up pass (they overlap the previous frame's tile kernel; a handle's first frame needs neither); copy: batch read-back.
     // Handles that render at the same time share them: order is kept by events, sharing only serialises their plan chains.
     hipStream_t side = nullptr, side2 = nullptr, copy = nullptr;
+    uint8_t *d_maps = nullptr;   // [kMaxStripeMaps][kMaxStripes] owner tables of the registered stripe maps, uploaded on first use (vf_stitch_tiles_device)
+    uint64_t maps_uploaded = 0;  // bit k: map k is there
 };
 
 struct vf_terrain {
@@ -150,8 +180,7 @@ struct vf_terrain {
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
                                          // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
-        uint8_t *slab = nullptr;         // one allocation per plan state, made when the state is first used: a handle that renders ONE frame
-                                         // (the reference's usage: construct, render_png once) never pays for the second state's 0.4 GB
+        uint8_t *slab = nullptr;         // one allocation per plan state
         float u_used[32] = {};           // view + proj of the frame whose tile times sit in `feedback` (the plan looks them up through the camera motion)
         bool have_u_used = false;
     } ps[kPlanStates];
@@ -168,6 +197,8 @@ struct vf_terrain {
     uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
     hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
+    uint8_t *d_stripe_owner = nullptr;   // tile shards with a registered stripe map: owner per column stripe (kMaxStripes bytes)
+    bool use_map = false;
     uint32_t *d_merge = nullptr;         // where the depth slices of a heavy tile meet: [tiles][16] arrival counters, then [tiles][64 x 64] ids; zero between frames
     bool shard_tiles = false;
     uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
@@ -190,9 +221,12 @@ struct vf_terrain {
     // cut (C4: groups -7 % on the top-down camera at any rank count, -1.5 % on one GPU at the default camera, +5 % on a rank of eight,
     // whose items are narrow strips).  Never a difference in the picture.  groups_mode: -1 measure and choose, 0 / 1 fixed.
     int groups_mode = -1;
-    // A probe = an event at the end of a frame's work on the draw stream; a sample = the time between the ends of two consecutive
-    // frames drawn by the SAME variant: the frame period, the very thing to be minimised, whether frames overlap or wait for each other.
-    struct GroupProbe { hipEvent_t b = nullptr; int variant = 0; uint32_t seq = 0, epoch = 0; bool pending = false, valid = false; } gprobe[16];
+    // A probe = two events around a frame's kernels on the draw stream (k_clear + the tile launches); a sample = the time between them.
+    // (Round 4 sampled the frame PERIOD between two consecutive frames of one variant, in runs AAABBB: right for a camera at rest, but a
+    //  moving camera's frames differ in cost by +-20 % from pose to pose and a run of three A's sat on other poses than the B's -- on the
+    //  C5 orbit the handle kept the slower variant in the bench, 0.326 instead of 0.305 ms per pose.  Round 5: every probed frame is a
+    //  sample of its own, the variants alternate ABBA ABBA ..., so any linear drift of the cost over the window cancels exactly.)
+    struct GroupProbe { hipEvent_t a = nullptr, b = nullptr; int variant = 0; uint32_t seq = 0, epoch = 0; bool pending = false, valid = false; } gprobe[16];
     uint32_t gprobe_head = 0, g_epoch_id = 0;
     float g_ms[2] = { 0.0f, 0.0f };      // frame period with each variant in this epoch (mean of the samples taken)
     uint32_t g_n[2] = { 0u, 0u };
@@ -275,6 +309,7 @@ void vf_ctx_destroy(vf_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_thresh) (void)hipFree(c->d_thresh);
+    if (c->d_maps) (void)hipFree(c->d_maps);
     for (hipStream_t q : { c->side, c->side2, c->copy }) if (q) (void)hipStreamDestroy(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -431,12 +466,15 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     C.add((void **)&t->d_lut, sizeof lut);
     C.add((void **)&t->d_rgba_own, all_tiles * kTileW * kTileH * sizeof(uint32_t));   // whole tiles: tile-major shards need the padding
     C.add((void **)&t->d_tile_map, all_tiles * sizeof(uint32_t));
+    C.add((void **)&t->d_stripe_owner, kMaxStripes);
     err = C.commit(&t->slab, ctx->stream);
     // (the two side streams are made by the handle's SECOND frame: a stream costs ~2 ms to create and as much to destroy, and a
     //  handle's first frame -- the only one of the reference's construct / render_png once usage -- has nothing to overlap with)
     if (err == hipSuccess) err = hipMemcpyAsync(t->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, ctx->stream);   // (pageable source: returns when the copy is staged)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&t->entry, hipEventDisableTiming);
-    if (err == hipSuccess) err = ensure_plan_state(t, 0, ctx->stream);
+    // (both plan states now: a device allocation costs 0.03 ms whatever its size -- measured, round 5 -- while making the second one
+    //  inside the handle's second frame cost that frame 0.7 ms)
+    for (uint32_t k = 0; k < vf_terrain::kPlanStates && err == hipSuccess; ++k) err = ensure_plan_state(t, k, ctx->stream);
     if (err != hipSuccess) {
         std::string m = std::string("terrain allocation failed: ") + hipGetErrorString(err);
         vf_terrain_destroy(t);
@@ -476,7 +514,7 @@ void vf_terrain_destroy(vf_terrain *t)
     if (t->h_png_first) std::free(t->h_png_first);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
-    for (auto &g : t->gprobe) { if (g.b) (void)hipEventDestroy(g.b); }
+    for (auto &g : t->gprobe) { if (g.a) (void)hipEventDestroy(g.a); if (g.b) (void)hipEventDestroy(g.b); }
     delete t;
 }
 
@@ -585,7 +623,7 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     t->rank = rank; t->nranks = nranks; t->band_h = band_h;
-    t->shard_tiles = false;
+    t->shard_tiles = false; t->use_map = false;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
     t->local_tiles = t->ntx * ((t->local_rows + kTileH - 1) / kTileH);
     t->rendered = false; t->have_frame = false;
@@ -606,13 +644,16 @@ int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nran
 {
     if (!count) return fail(VF_ERR_INVALID, "NULL argument");
     if (width == 0 || height == 0 || nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "empty frame or rank >= nranks");
-    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word has bits above VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15)");
+    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word is neither VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15) nor a registered stripe map");
     const uint32_t ntx = (width + kTileW - 1) / kTileW, nty = (height + kTileH - 1) / kTileH;
     if (ntx > 0xFFFFu || nty > 0xFFFFu) return fail(VF_ERR_INVALID, "frame too large");
+    const StripeMap *m = layout_map(skew);
+    if (m && (m->nranks != nranks || ((ntx - 1u) >> m->shift) >= m->owner.size()))
+        return fail(VF_ERR_INVALID, "the registered stripe map was made for another number of ranks or a narrower frame");
     uint32_t n = 0;
     for (uint32_t ty = 0; ty < nty; ++ty)
         for (uint32_t tx = 0; tx < ntx; ++tx)
-            if (((tx >> layout_shift(skew)) + layout_skew(skew) * ty) % nranks == rank) {
+            if (layout_owner(skew, m, tx, ty, nranks) == rank) {
                 if (tiles && n < capacity) tiles[n] = tx | (ty << 16);
                 ++n;
             }
@@ -620,17 +661,104 @@ int vf_tile_layout(uint32_t width, uint32_t height, uint32_t rank, uint32_t nran
     return VF_OK;
 }
 
+int vf_tile_layout_register_map(const uint8_t *stripe_owner, uint32_t nstripes, uint32_t stripe_log2, uint32_t nranks, uint32_t *layout)
+{
+    if (!stripe_owner || !layout) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nstripes == 0 || nstripes > kMaxStripes || stripe_log2 > 15u || nranks == 0 || nranks > 255u) return fail(VF_ERR_INVALID, "1..256 stripes, stripe_log2 <= 15, 1..255 ranks");
+    for (uint32_t k = 0; k < nstripes; ++k) if (stripe_owner[k] >= nranks) return fail(VF_ERR_INVALID, "a stripe's owner is not a rank");
+    std::lock_guard<std::mutex> lk(g_maps_mu);
+    g_maps.reserve(kMaxStripeMaps);                        // (never reallocated: layout_map hands out pointers)
+    for (uint32_t id = 0; id < g_maps.size(); ++id)        // the same table again: the same word (every rank registers its own copy)
+        if (g_maps[id].shift == stripe_log2 && g_maps[id].nranks == nranks && g_maps[id].owner.size() == nstripes &&
+            std::memcmp(g_maps[id].owner.data(), stripe_owner, nstripes) == 0) { *layout = kLayoutMapBit | (id << 21) | (stripe_log2 << 16); return VF_OK; }
+    if (g_maps.size() >= kMaxStripeMaps) return fail(VF_ERR_INVALID, "too many registered stripe maps (64 per process)");
+    StripeMap m;
+    m.owner.assign(stripe_owner, stripe_owner + nstripes); m.shift = stripe_log2; m.nranks = nranks;
+    g_maps.push_back(std::move(m));
+    *layout = kLayoutMapBit | ((uint32_t)(g_maps.size() - 1u) << 21) | (stripe_log2 << 16);
+    return VF_OK;
+}
+
+int vf_balance_stripes(const float *stripe_ms, uint32_t nstripes, uint32_t nranks, uint8_t *stripe_owner)
+{
+    if (!stripe_ms || !stripe_owner) return fail(VF_ERR_INVALID, "NULL argument");
+    if (nranks == 0 || nranks > 255u || nstripes == 0 || nstripes > kMaxStripes || nstripes % nranks) return fail(VF_ERR_INVALID, "the stripes must divide evenly among 1..255 ranks");
+    // Heaviest stripe first, each to the least loaded rank that still has room (every rank ends up with nstripes / nranks stripes: the
+    // slabs and the exchange's chunks keep their sizes); then stripes of the most loaded rank are swapped against lighter ones of the
+    // others for as long as that lowers the heavier of the two loads; and the round-robin deal itself is kept when nothing beat it.
+    // Ties by stripe number / rank number: the same input gives the same table on every rank.  Times that are not finite count as zero.
+    std::vector<uint32_t> order(nstripes);
+    for (uint32_t k = 0; k < nstripes; ++k) order[k] = k;
+    auto cost = [&](uint32_t k) { const float v = stripe_ms[k]; return std::isfinite(v) && v > 0.0f ? (double)v : 0.0; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+    std::vector<double> load(nranks, 0.0);
+    std::vector<uint32_t> have(nranks, 0u);
+    std::vector<uint8_t> own(nstripes, 0);
+    const uint32_t room = nstripes / nranks;
+    for (uint32_t k : order) {
+        uint32_t best = nranks;
+        for (uint32_t r = 0; r < nranks; ++r)
+            if (have[r] < room && (best == nranks || load[r] < load[best])) best = r;
+        own[k] = (uint8_t)best; load[best] += cost(k); have[best]++;
+    }
+    for (uint32_t round = 0; round < 4u * nstripes; ++round) {
+        uint32_t hot = 0;
+        for (uint32_t r = 1; r < nranks; ++r) if (load[r] > load[hot]) hot = r;
+        double gain = 1e-12 * (load[hot] + 1.0);
+        uint32_t sa = nstripes, sb = nstripes;
+        for (uint32_t a = 0; a < nstripes; ++a) {
+            if (own[a] != hot) continue;
+            for (uint32_t b = 0; b < nstripes; ++b) {
+                const uint32_t r = own[b];
+                if (r == hot || !(cost(b) < cost(a))) continue;
+                const double d = cost(a) - cost(b);         // moves from the hot rank to r
+                const double worst = std::fmax(load[hot] - d, load[r] + d);
+                if (load[hot] - worst > gain) { gain = load[hot] - worst; sa = a; sb = b; }
+            }
+        }
+        if (sa == nstripes) break;
+        const uint32_t r = own[sb];
+        const double d = cost(sa) - cost(sb);
+        load[hot] -= d; load[r] += d; own[sa] = (uint8_t)r; own[sb] = (uint8_t)hot;
+    }
+    std::vector<double> rr(nranks, 0.0);
+    for (uint32_t k = 0; k < nstripes; ++k) rr[k % nranks] += cost(k);
+    const bool keep_round_robin = *std::max_element(rr.begin(), rr.end()) <= *std::max_element(load.begin(), load.end());
+    for (uint32_t k = 0; k < nstripes; ++k) stripe_owner[k] = keep_round_robin ? (uint8_t)(k % nranks) : own[k];
+    return VF_OK;
+}
+
+int vf_terrain_tile_times(vf_terrain *t, float *ms, uint32_t capacity, uint32_t *count)
+{
+    if (!t || !count) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->rendered) return fail(VF_ERR_INVALID, "nothing rendered yet");
+    int rc = vf_terrain_sync(t);
+    if (rc != VF_OK) return rc;
+    const uint32_t n = std::min(capacity, t->local_tiles);
+    std::vector<uint32_t> ticks(n);
+    if (n && ms) {
+        VF_HIP_TRY(hipMemcpy(ticks.data(), t->ps[t->last_set].feedback, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < n; ++k) ms[k] = (float)ticks[k] * 1e-5f;      // 10 ns ticks of the 100 MHz clock
+    }
+    *count = t->local_tiles;
+    return VF_OK;
+}
+
 int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t skew)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (nranks == 0 || rank >= nranks) return fail(VF_ERR_INVALID, "rank must be < nranks");
-    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word has bits above VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15)");
+    if (!layout_valid(skew)) return fail(VF_ERR_INVALID, "layout word is neither VF_TILE_LAYOUT(skew < 65536, stripe_log2 <= 15) nor a registered stripe map");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
     std::vector<uint32_t> map((size_t)t->ntx * t->nty);
     uint32_t n = 0;
     int rc = vf_tile_layout(t->W, t->H, rank, nranks, skew, map.data(), (uint32_t)map.size(), &n);
     if (rc != VF_OK) return rc;
+    VF_HIP_TRY(sync_sides(t));                                // (k_block_boxes of a frame in flight reads the owner table)
+    const StripeMap *sm = layout_map(skew);
+    if (sm) VF_HIP_TRY(hipMemcpy(t->d_stripe_owner, sm->owner.data(), sm->owner.size(), hipMemcpyHostToDevice));
+    t->use_map = sm != nullptr;
     if (n) VF_HIP_TRY(hipMemcpy(t->d_tile_map, map.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
     t->shard_tiles = true; t->local_tiles = n;
     t->rank = rank; t->nranks = nranks; t->skew = skew;
@@ -709,6 +837,7 @@ static void build_params(const vf_terrain *t, FrameParams &P)
     P.rank = t->rank; P.nranks = t->nranks; P.band_h = t->band_h; P.band_shift = ilog2(t->band_h);
     P.local_rows = t->local_rows;
     P.shard_tiles = t->shard_tiles ? 1u : 0u; P.tile_map = t->d_tile_map; P.skew = layout_skew(t->skew); P.stripe_shift = layout_shift(t->skew);
+    P.stripe_owner = t->shard_tiles && t->use_map ? t->d_stripe_owner : nullptr;
     P.shade_mode = t->shade_mode; P.tex = t->d_height;
     P.inv2hr = 1.0f / (2.0f * P.h_range);
     {   // cell / nm1 as mulhi(cell, m) >> s, exact for cell < 2^26 (nm1 < 2^13): s = 31 + ceil(log2 nm1) - 32, m = ceil(2^(s + 32) / nm1)
@@ -804,7 +933,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     t->frame_no++;
     // A handle's FIRST frame runs on the caller's stream alone, plan and set-up included: its chain is serial anyway (the static plan
     // estimate reads the set-up pass's records) and there is no earlier frame to hide anything under.  The side streams and the second
-    // plan state are made by the second frame.
+    // plan chain's events come into play with the second frame.
     const bool solo = !t->side && t->frame_no == 1u;
     if (!solo && !t->side) {
         vf_ctx *c = t->ctx;                                  // (borrowed from the context: made once per process)
@@ -941,45 +1070,47 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     if (!VF_GROUPED) pick = 0;
     else if (forced >= 0) pick = forced != 0;
     else {
-        // probes that have completed (frames behind us: never a wait): a frame whose predecessor was probed too, and drawn by the same
-        // variant, yields a sample -- the time from that frame's end to its own
+        // probes that have completed (frames behind us: never a wait): every probed frame is a sample -- the time its kernels took on
+        // the draw stream.  (hipEventQuery's "not ready" is cleared below: the plan launches' errors were collected above.)
         for (auto &g : t->gprobe)
             if (g.pending && hipEventQuery(g.b) == hipSuccess) {
                 g.pending = false;
-                for (const auto &q : t->gprobe)
-                    if (q.valid && !q.pending && q.epoch == g.epoch && q.seq + 1u == g.seq && q.variant == g.variant) {
-                        float ms = 0.0f;
-                        if (hipEventElapsedTime(&ms, q.b, g.b) == hipSuccess && ms > 0.0f) {
-                            // the probe window's samples count alike; a later look weighs as much as all before it (the view may have drifted)
-                            const uint32_t n = ++t->g_n[g.variant];
-                            t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 4u ? n : 2u);
-                        }
-                    }
+                float ms = 0.0f;
+                if (g.epoch == t->g_epoch_id && hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && ms > 0.0f) {
+                    // the probe window's samples count alike; a later look weighs as much as all before it (the view may have drifted)
+                    const uint32_t n = ++t->g_n[g.variant];
+                    t->g_ms[g.variant] += (ms - t->g_ms[g.variant]) / (float)(n <= 8u ? n : 2u);
+                }
             }
-        (void)hipGetLastError();                           // (hipEventQuery's "not ready" is not an error of this frame)
+        (void)hipGetLastError();
         // what was measured belongs to another layout, or to the view before the camera started to move (a camera that keeps moving
-        // keeps its choice -- an orbit's poses differ little in what suits them -- and is looked at again every kAgain frames)
+        // keeps its choice and is looked at again every kAgain frames)
         if (t->frames_since_reset <= 1 || motion_starts) { t->g_epoch_frames = 0; t->g_epoch_id++; t->g_n[0] = t->g_n[1] = 0; t->g_ms[0] = t->g_ms[1] = 0.0f; }
-        // the plan settles for four frames on the default variant; then twelve frames AAABBBAAABBB -- interleaved, so that what is left
-        // of the plan's settling weighs on both alike, in runs of three, so that every run yields two periods between frames of one
-        // variant; then the faster one, looked at again now and then (four frames: AABB)
+        // the plan settles for four frames on the default variant; then sixteen frames ABBA ABBA ABBA ABBA (both variants see the same
+        // mean position in the window: a drift of the frame cost -- the plan still settling, a camera under way -- cancels); then the
+        // faster one, looked at again now and then (four frames, ABBA)
         const uint32_t e = t->g_epoch_frames++;
-        constexpr uint32_t kSettle = 4, kProbe = 12, kAgain = 128;
+        constexpr uint32_t kSettle = 4, kProbe = 16, kAgain = 128;
+        auto abba = [](uint32_t k) -> int { return (int)(((k & 3u) == 1u || (k & 3u) == 2u) ? 1u : 0u); };
         if (e < kSettle) pick = guess;
-        else if (e < kSettle + kProbe) pick = guess ^ (int)(((e - kSettle) / 3u) & 1u);
+        else if (e < kSettle + kProbe) pick = guess ^ abba(e - kSettle);
         else if (t->g_n[0] && t->g_n[1]) {
             pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
-            if (e % kAgain >= kAgain - 2u) pick = !pick;          // (two frames of the other variant -- behind two timed ones of this -- keep the periods current)
+            if (e % kAgain >= kAgain - 4u) pick ^= abba(e % kAgain - (kAgain - 4u)) ^ 1;      // B A A B seen from the variant in use: two frames of the other one
         }
+        // (no samples yet -- a host that queues frames faster than the GPU draws them is past the window before its first probe
+        //  completes: the default stays until they arrive; they are taken whenever they complete)
     }
     t->groups_now = pick;
     const bool groups = pick != 0;
     // timed: the frames of the probe window (from the last settle frame on), and now and then two frames of each variant (one event each)
     const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
-    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 3u && e_now < 16u) || e_now % 128u >= 124u);
+    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 4u && e_now < 20u) || (e_now >= 20u && e_now % 128u >= 124u));
     vf_terrain::GroupProbe *gp = nullptr;
     if (probe) { gp = &t->gprobe[t->gprobe_head++ % 16]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
-    if (gp && !gp->b && hipEventCreate(&gp->b) != hipSuccess) { gp->b = nullptr; gp = nullptr; }   // (made on first use: a one-shot handle never probes)
+    if (gp && !gp->b && (hipEventCreate(&gp->a) != hipSuccess || hipEventCreate(&gp->b) != hipSuccess)) gp = nullptr;   // (made on first use: a one-shot handle never probes)
+    if (gp && (!gp->a || !gp->b)) gp = nullptr;
+    if (gp) (void)hipEventRecord(gp->a, s);
     if (ntiles) {
         uint32_t *vis = write_vis ? t->d_vis : nullptr;
         hipLaunchKernelGGL(k_clear, dim3(ntiles), dim3(256), 0, s, P, S.background, t->d_rgba, vis, stats, nstats, seg_count);
@@ -1754,8 +1885,18 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     // persistent, about one small workgroup per CU (VF_STITCH_WGS overrides): it has to fit beside the next frame's tile kernel
     uint32_t wgs = (uint32_t)std::max(1, ctx->prop.multiProcessorCount);
     if (const char *e = std::getenv("VF_STITCH_WGS")) wgs = (uint32_t)std::max(1, std::atoi(e));
+    const uint8_t *d_owner = nullptr;
+    if (const StripeMap *m = layout_map(skew)) {            // a registered stripe map: its owner table on this device (uploaded once per context)
+        const uint32_t id = (skew >> 21) & 0x3Fu;
+        if (!ctx->d_maps) VF_HIP_TRY(hipMalloc(&ctx->d_maps, (size_t)kMaxStripeMaps * kMaxStripes));
+        if (!((ctx->maps_uploaded >> id) & 1ull)) {
+            VF_HIP_TRY(hipMemcpy(ctx->d_maps + (size_t)id * kMaxStripes, m->owner.data(), m->owner.size(), hipMemcpyHostToDevice));
+            ctx->maps_uploaded |= 1ull << id;
+        }
+        d_owner = ctx->d_maps + (size_t)id * kMaxStripes;
+    }
     hipLaunchKernelGGL(k_stitch_tiles, dim3(std::min(ntx * nty, wgs)), dim3(256), 0, s, (const uint32_t *)dev_gathered, (uint32_t *)dev_image, width, height,
-                       ntx, nty, nranks, layout_skew(skew), layout_shift(skew), stride_tiles);
+                       ntx, nty, nranks, layout_skew(skew), layout_shift(skew), stride_tiles, d_owner);
     VF_HIP_TRY(hipGetLastError());
     return VF_OK;
 }

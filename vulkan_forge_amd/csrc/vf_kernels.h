@@ -198,8 +198,11 @@ __global__ __launch_bounds__(512) void k_block_boxes(FrameParams P, const float2
             if (P.shard_tiles) {
                 const uint32_t tx0 = ((uint32_t)r.x0 / kTileW) >> P.stripe_shift, tx1 = ((uint32_t)r.x1 / kTileW) >> P.stripe_shift;     // stripes (groups of tile columns)
                 const uint32_t ty0 = (uint32_t)r.y0 / kTileH, ty1 = (uint32_t)r.y1 / kTileH;
-                if (tx1 - tx0 + 1u >= P.nranks) mine = true;             // a full period of stripes: every rank owns one in each row
-                for (uint32_t ty = ty0; ty <= ty1 && !mine; ++ty) {
+                if (P.stripe_owner) {                                       // a registered stripe map: an owner per stripe (column stripes: rows do not matter)
+                    for (uint32_t sc = tx0; sc <= tx1 && !mine; ++sc) mine = P.stripe_owner[sc] == P.rank;
+                }
+                else if (tx1 - tx0 + 1u >= P.nranks) mine = true;        // a full period of stripes: every rank owns one in each row
+                for (uint32_t ty = ty0; ty <= ty1 && !mine && !P.stripe_owner; ++ty) {
                     // owner(tx, ty) = ((tx >> stripe_shift) + skew ty) % nranks: the first stripe >= tx0 this rank owns in row ty
                     const uint32_t want = (P.rank + P.nranks - (P.skew * ty) % P.nranks) % P.nranks;
                     const uint32_t first = tx0 + (want + P.nranks - tx0 % P.nranks) % P.nranks;
@@ -2508,19 +2511,31 @@ __device__ __forceinline__ uint32_t owned_left_of(uint32_t tx_end, uint32_t want
     const uint32_t full = g_end > want ? (g_end - 1u - want) / nranks + 1u : 0u;          // owned stripes wholly left of tx_end
     return (full << shift) + (g_end % nranks == want ? rem : 0u);
 }
+// ... and under a registered stripe map (`owner` per column stripe)
+__device__ __forceinline__ uint32_t owned_left_of_map(const uint8_t *__restrict__ owner, uint32_t tx_end, uint32_t r, uint32_t shift)
+{
+    uint32_t n = 0;
+    for (uint32_t g = 0; (g << shift) < tx_end; ++g)
+        if (owner[g] == r) n += min((g + 1u) << shift, tx_end) - (g << shift);
+    return n;
+}
 __global__ __launch_bounds__(256) void k_stitch_tiles(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t W, uint32_t H,
-                                                      uint32_t ntx, uint32_t nty, uint32_t nranks, uint32_t skew, uint32_t shift, uint32_t stride_tiles)
+                                                      uint32_t ntx, uint32_t nty, uint32_t nranks, uint32_t skew, uint32_t shift, uint32_t stride_tiles,
+                                                      const uint8_t *__restrict__ owner)
 {
     __shared__ uint32_t s_local;
     const bool wide = (W & 3u) == 0u && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0u;
     for (uint32_t tile = blockIdx.x; tile < ntx * nty; tile += gridDim.x) {
         const uint32_t tx = tile % ntx, ty = tile / ntx;
-        const uint32_t r = ((tx >> shift) + skew * ty) % nranks;
+        const uint32_t r = owner ? owner[tx >> shift] : ((tx >> shift) + skew * ty) % nranks;
         __syncthreads();                                   // (the previous tile's s_local has been read)
         if (threadIdx.x == 0) {
             uint32_t before = 0;                           // tiles of rank r in the rows above
+            if (owner) s_local = ty * owned_left_of_map(owner, ntx, r, shift) + owned_left_of_map(owner, tx, r, shift);
+            else {
             for (uint32_t t = 0; t < ty; ++t) before += owned_left_of(ntx, (r + nranks - (skew * t) % nranks) % nranks, nranks, shift);
             s_local = before + owned_left_of(tx, (r + nranks - (skew * ty) % nranks) % nranks, nranks, shift);
+            }
         }
         __syncthreads();
         const uint32_t *tp = src + ((size_t)r * stride_tiles + s_local) * (kTileW * kTileH);

@@ -105,6 +105,26 @@ def default_stripe_log2(nranks: int, ntx: int = 0) -> int:
     return sh
 
 
+def layout_stripe_log2(layout: int) -> int:
+    """log2 of the stripe width of a layout word (a plain VF_TILE_LAYOUT word or a registered stripe map's)."""
+    return (int(layout) >> 16) & 0xF
+
+
+def stripe_times(tile_ms, tiles, nstripes: int, stripe_log2: int):
+    """Per-stripe sums of a rank's per-tile times (`tiles`: its (tx, ty) list in storage order, `tile_ms` in the same order)."""
+    import numpy as np
+    tiles = np.asarray(tiles).reshape(-1, 2)
+    return np.bincount(tiles[:, 0] >> stripe_log2, weights=np.asarray(tile_ms, np.float64)[:len(tiles)], minlength=nstripes).astype(np.float32)[:nstripes]
+
+
+def balanced_layout(stripe_ms, nranks: int, stripe_log2: int) -> int:
+    """Per-stripe times (summed over all ranks: identical on every rank) -> the layout word of the load-balanced stripe map:
+    vf_balance_stripes (heaviest stripe first to the least loaded rank with room; every rank keeps the same number of stripes, so the
+    exchange's sizes do not change) + vf_tile_layout_register_map."""
+    from . import cabi
+    return cabi.register_stripe_map(cabi.balance_stripes(stripe_ms, nranks), stripe_log2, nranks)
+
+
 def tile_layout(width: int, height: int, rank: int, nranks: int, skew: int):
     """(n, 2) array of (tx, ty): the tiles of `rank` in storage order (the library's vf_tile_layout; host arithmetic)."""
     from . import cabi
@@ -190,15 +210,18 @@ class BandStitchExchange:
     Double-buffered like `TileExchange`; `stitch(recv, band_image, band_rows)` is the caller's (the C-ABI's stitch kernel on the
     GPU, NumPy in the CPU tests).  Works on CUDA tensors with nccl (RCCL) and on CPU tensors with gloo."""
 
-    def __init__(self, width, height, device, depth=2, dst=0, group=None, stripe_log2=0):
+    def __init__(self, width, height, device, depth=2, dst=0, group=None, stripe_log2=0, layout=None):
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.dst, self.torch = dist, group, dst, torch
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if layout is not None:
+            stripe_log2 = layout_stripe_log2(layout)       # a registered stripe map (balanced_layout): same sizes, other owners
         if not band_exchange_applies(width, height, self.world, stripe_log2):
             raise ValueError("BandStitchExchange needs stripes that divide the tile columns evenly among the ranks and tile rows that divide by their number")
-        self.W, self.H, self.skew, self.depth = width, height, layout_code(0, stripe_log2), depth     # `skew`: the layout word (column stripes)
+        # `skew`: the layout word (column stripes); may be replaced by a registered map's word of the same stripe width (set_layout)
+        self.W, self.H, self.skew, self.depth = width, height, (layout_code(0, stripe_log2) if layout is None else int(layout)), depth
         ntx, nty = width // TILE, height // TILE
         self.band_rows = height // self.world                         # pixel rows per band
         self.chunk_tiles = (nty // self.world) * (ntx // self.world)  # tiles one rank holds of one band
@@ -210,6 +233,11 @@ class BandStitchExchange:
 
     def output(self, slot):
         return self.local[slot]
+
+    def set_layout(self, layout):
+        """Another deal of the same stripes (a registered stripe map: every rank keeps its number of stripes, so nothing is resized)."""
+        assert layout_stripe_log2(layout) == layout_stripe_log2(self.skew)
+        self.skew = int(layout)
 
     def exchange(self, slot, stitch, image):
         """Frame in `output(slot)` -> rows of `image` ((H, W, 4) uint8, used on `dst`).  Ordered on the caller's current stream
