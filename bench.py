@@ -205,8 +205,13 @@ def main():
     height_host = rng.random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
     d_height = torch.from_numpy(height_host).to(dev)              # inputs resident in HBM before the timed region
 
+    main_handle = []
+
     def new_handle():
-        h = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank)
+        # one context per process and device, like the drop-in module's (its stream and the side streams handles borrow are made once)
+        h = cabi.Terrain(W, H, G, lut, lut_is_srgb=True, device=local_rank, share_ctx=main_handle[0] if main_handle else None)
+        if not main_handle:
+            main_handle.append(h)
         h.set_height_device(d_height.data_ptr(), G, G)
         return h
 

@@ -26,4 +26,6 @@ if os.environ.get("VF_C5_STATIC"):
         t.sync(); t0 = time.perf_counter()
         for _ in range(40): t.render()
         t.sync(); print(f"   pose {k} with the camera at rest: {(time.perf_counter() - t0) / 40 * 1e3:.4f} ms per frame", flush=True)
+if os.environ.get("VF_C5_POSES"):
+    print("   tile kernel per pose, last lap (ms):", " ".join(f"{x:.2f}" for x in tile), flush=True)
 print(f"{(sys.argv[1] if len(sys.argv) > 1 else 'default'):28s} ms per pose, three laps: {laps[0]:.4f} {laps[1]:.4f} {laps[2]:.4f}   last lap: tile kernel mean {tile.mean():.4f} median {np.median(tile):.4f}  period median {np.median(period[1:]):.4f}  line loop in use: {t.raster_groups()[0]}", flush=True)

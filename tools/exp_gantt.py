@@ -9,13 +9,19 @@ from vulkan_forge_amd import cabi
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 W = H = G = 4096
+if os.environ.get("VF_C5"): W, H, G = 1920, 1080, 2048            # BASELINE config 5's frame; camera "poseK" = pose K of the orbit, at rest
 cam = sys.argv[1] if len(sys.argv) > 1 else "default"
 shard = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None
-h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
-t = cabi.Terrain(W, H, G, vf.colormap_rgba8("viridis")); t.set_height(h); t.set_uniforms(b.camera_uniforms(cam, W, H))
+h = np.random.default_rng(20250817 if os.environ.get("VF_C5") else 20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+t = cabi.Terrain(W, H, G, vf.colormap_rgba8("viridis")); t.set_height(h); t.set_uniforms(b.orbit_uniforms(int(cam[4:]), W, H) if cam.startswith("pose") else b.orbit_uniforms(0, W, H) if cam.startswith("orbit") else b.camera_uniforms(cam, W, H))
 if shard: t.set_tile_shard(shard[0], shard[1], (int(sys.argv[4]) << 16) if len(sys.argv) > 4 else 0)
-for _ in range(30): t.render()
-for rep in range(2):
+moving = cam.startswith("orbit")                       # "orbitK": the poses 0 .. K of the orbit one after another (a moving camera); the schedule of pose K
+if moving:
+    for k in range(64 + int(cam[5:])): t.set_uniforms(b.orbit_uniforms(k % 64, W, H)); t.render()
+else:
+    for _ in range(30): t.render()
+for rep in range(1 if moving else 2):
+    if moving: t.set_uniforms(b.orbit_uniforms((int(cam[5:]) + 1) % 64, W, H))
     t.enable_timing(True); t.render(); tm = t.timings(); it = t.item_stats(); t.enable_timing(False)
     start = it[:, 1].astype(np.int64); start -= start.min()
     dur = it[:, 3].astype(np.int64)

@@ -6,13 +6,14 @@ from vulkan_forge_amd import cabi
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 W = H = G = int(os.environ.get("VF_SIZE", 4096))
+if os.environ.get("VF_C5"): W, H, G = 1920, 1080, 2048            # BASELINE config 5's frame; cameras: orbit poses 8 (the default eye) and 0
 import vulkan_forge_amd as _vf; lut = _vf.colormap_rgba8("viridis")
-h = np.random.default_rng(20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
+h = np.random.default_rng(20250817 if os.environ.get("VF_C5") else 20250816).random((G, G), dtype=np.float32) * np.float32(0.5) - np.float32(0.25)
 names = ["setup", "pull/cull", "vertex", "classify", "span raster", "completion/rescan", "chunk-end wait", "fragment"]
 t = cabi.Terrain(W, H, G, lut, lib=cabi.load(sys.argv[1])); t.set_height(h)
 if len(sys.argv) > 3: t.set_tile_shard(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)      # one rank of N
-for cam in ("default", "fill"):
-    t.set_uniforms(b.camera_uniforms(cam, W, H))
+for cam in (("pose8", "pose0") if os.environ.get("VF_C5") else ("default", "fill")):
+    t.set_uniforms(b.orbit_uniforms(int(cam[4:]), W, H) if cam.startswith("pose") else b.camera_uniforms(cam, W, H))
     for _ in range(24): t.render()
     t.enable_timing(True); t.render(); tm = t.timings(); ph = t.phase_cycles().astype(float); it = t.item_stats(); t.enable_timing(False)
     vsub2 = ph[32:34]; vsub = ph[30:32]; wv = ph[24:30]; sub = ph[16:24]; cnt = ph[8:16]; ph = ph[:8]; ph[0] += sub.sum(); ph[2] += vsub.sum() + vsub2.sum()

@@ -165,11 +165,17 @@ def register_stripe_map(stripe_owner, stripe_log2, nranks, lib=None):
 class Terrain:
     """Thin RAII wrapper over vf_ctx + vf_terrain for callers that pass raw device pointers / streams."""
 
-    def __init__(self, width, height, grid, lut_rgba8, lut_is_srgb=True, device=0, lib=None):
+    def __init__(self, width, height, grid, lut_rgba8, lut_is_srgb=True, device=0, lib=None, share_ctx=None):
+        """`share_ctx`: another Terrain whose context (vf_ctx: device, stream, the side streams handles borrow) this one uses too -- what the
+        drop-in module does for every object of a process (one context per process and device); the other Terrain must outlive this one."""
         self.lib = lib or load()
         self.W, self.H, self.grid = int(width), int(height), int(grid)
         self.ctx, self.t = _vp(), _vp()
-        self._check(self.lib.vf_ctx_create(int(device), C.byref(self.ctx)))
+        self._own_ctx = share_ctx is None
+        if share_ctx is None:
+            self._check(self.lib.vf_ctx_create(int(device), C.byref(self.ctx)))
+        else:
+            self.ctx = share_ctx.ctx
         lut = np.ascontiguousarray(lut_rgba8, dtype=np.uint8).reshape(1024)
         self._check(self.lib.vf_terrain_create(self.ctx, self.W, self.H, self.grid, lut.ctypes.data, int(bool(lut_is_srgb)),
                                                C.byref(self.t)))
@@ -184,7 +190,8 @@ class Terrain:
             self.lib.vf_terrain_destroy(self.t)
             self.t = _vp()
         if self.ctx:
-            self.lib.vf_ctx_destroy(self.ctx)
+            if self._own_ctx:
+                self.lib.vf_ctx_destroy(self.ctx)
             self.ctx = _vp()
 
     def __del__(self):

@@ -1191,10 +1191,25 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             // 0.52 ms whatever came before).  Shards keep the face value: their cold-start fixed point is the better one for a
             // GPU with few tiles (emulated 2 / 4 ranks: 0.74 / 0.52 ms against 0.84 / 0.55), and their camera rarely moves.
             const bool as_one = P.nranks == 1u && !P.shard_tiles;
+#ifndef VF_PEAK_CUT
+#define VF_PEAK_CUT 1
+#endif
             auto tile_time = [&](uint32_t idx) -> uint32_t {
-                const uint32_t t = last_blocks[idx];
+                uint32_t t = last_blocks[idx];
                 const uint32_t f = last_flags[idx];            // bits 8..11 log2(strips), 12..13 log2(slices) of the frame the time comes from
-                return as_one ? (uint32_t)(((unsigned long long)t * 4ull) / (4ull + ((f >> 8) & 15u) + ((f >> 12) & 3u))) : t;
+                const uint32_t lg = (f >> 8) & 15u;
+                // A tile cut into strips is as heavy as its HEAVIEST strip makes it (round 5): a silhouette that crosses a corner of the tile
+                // leaves one strip with most of the work, and the tile's sum then says "cut in 8" where that strip alone outlasts the frame's
+                // even share several times -- at 1920 x 1080 (few tiles, a half-empty GPU) the frame waited for such strips with 47-65 % of
+                // the workgroups idle (tools/exp_gantt.py, VF_C5=1).  The strips' own times are in the 64 words behind the tile's.
+                const uint32_t lgp = lg + ((f >> 12) & 3u);     // log2 of the pieces the tile was cut into (strips x depth slices): <= 6, 64 words
+                if (VF_PEAK_CUT && t && lgp && lgp <= 6u) {
+                    const uint32_t *pc = last_blocks + (size_t)P.ntx * P.nty + 1u + (size_t)idx * 64u;
+                    uint32_t pk = 0;
+                    for (uint32_t p = 0; p < (1u << lgp); ++p) pk = max(pk, pc[p]);
+                    t = max(t, (uint32_t)min((unsigned long long)pk << lgp, 0xFFFFFFFFull));
+                }
+                return as_one ? (uint32_t)(((unsigned long long)t * 4ull) / (4ull + lg + ((f >> 12) & 3u))) : t;
             };
             uint32_t seen = tile_time(blockIdx.x);
             const uint32_t mean = *last_mean;
@@ -1222,6 +1237,24 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                                 if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, tile_time((uint32_t)y * P.ntx + (uint32_t)x));
                             }
                     }
+                }
+#ifndef VF_MM_SAMEPOS
+#define VF_MM_SAMEPOS 1
+#endif
+                // The plane is the ground: the silhouette's tiles show terrain ABOVE it -- at the horizon their centres lie beyond the plane's
+                // vanishing line and land nowhere, or on the light tiles under the ridge -- and those are the frame's heaviest tiles: left
+                // whole at the end of the queue one of them ran 0.5 ms after everything else had finished (C5 orbit, pose 16: 0.63 ms
+                // instead of 0.2).  So a tile also takes the heaviest time around its OWN place on the old screen (a ridge moves sideways
+                // under an orbiting camera, hardly up or down: two tiles to either side, one up and down) ...
+                // (C5 orbit: 0.302 -> 0.292 ms per pose; a floor from this frame's own block ranges -- the static estimate of a first frame --
+                //  under the cut or under the queue order: 0.300 .. 0.306, not kept)
+                if (VF_MM_SAMEPOS) {
+                    const int32_t tx = (int32_t)tp.tx, ty = (int32_t)(blockIdx.x / P.ntx);
+                    for (int32_t dy = -1; dy <= 1; ++dy)
+                        for (int32_t dx = -2; dx <= 2; ++dx) {
+                            const int32_t x = tx + dx, y = ty + dy;
+                            if (x >= 0 && y >= 0 && x < (int32_t)P.ntx && y < (int32_t)P.nty) seen = max(seen, tile_time((uint32_t)y * P.ntx + (uint32_t)x));
+                        }
                 }
             }
             else if ((seen == 0u || moving) && mean && P.nranks == 1u && !P.shard_tiles) {
