@@ -54,7 +54,7 @@ def copy(src, dst):
 
 open(os.path.join(P, f"{prefix}_bench.json"), "w").write(last_json_line(os.path.join(G, "bench.json")) + "\n")
 open(os.path.join(P, f"{prefix}_bench_c5.json"), "w").write(last_json_line(os.path.join(G, "bench_c5.json")) + "\n")
-for n in (2, 4):
+for n in (2, 4, 8):
     if os.path.exists(os.path.join(G, f"rehearse_{n}ranks.json")):
         open(os.path.join(P, f"{prefix}_rehearse_{n}ranks.json"), "w").write(last_json_line(os.path.join(G, f"rehearse_{n}ranks.json")) + "\n")
 copy("kernel_stats.csv", "kernel_stats.csv")
@@ -62,7 +62,8 @@ for n in ("fetch_default", "write_default", "frag_fetch_default", "frag_write_de
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
 for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log", "rank0_stitch.log", "cold.log", "fragment.log", "parity_soak.log"):
     copy(n, n)
-for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.log", "stripes.log", "hw_shift64_probe.log"):      # round 4
+for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.log", "stripes.log", "hw_shift64_probe.log",      # round 4
+          "one_shot.json", "c5_orbit.log", "c5_gantt.log", "tlb_l2_counters.txt", "stream_packets.log"):                                  # round 5
     if os.path.exists(os.path.join(G, n)):
         copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
