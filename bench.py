@@ -147,12 +147,12 @@ def host_cpus():
 
 
 def toolchain():
-    """the compiler the library in use was (or would be) built with, and its code-generation switches -- a compiler bump shows up here"""
+    """the compiler the library in use was built with and its code-generation switches, as __graft_entry__.build() recorded them next to
+    the library (nothing is executed here: under rocprofv3 --pmc the GPU is live before this program starts, and a GPU process must not
+    start another program in its place) -- a compiler bump shows up in the bench line"""
     try:
-        import __graft_entry__ as g
-        v = subprocess.run([g._hipcc(), "--version"], capture_output=True, text=True, timeout=30).stdout.splitlines()
-        keep = [ln.strip() for ln in v if ln.startswith("HIP version") or "clang version" in ln]
-        return {"hipcc": "; ".join(keep) or (v[0] if v else None), "tuning_flags": " ".join(g.HIPCC_TUNING)}
+        info = json.load(open(os.path.join(ROOT, "vulkan_forge_amd", "build_info.json")))
+        return {"hipcc": info.get("hipcc"), "tuning_flags": info.get("tuning_flags"), "built_lib_sha256": info.get("lib_sha256")}
     except Exception as e:  # noqa: BLE001
         return {"hipcc": None, "error": repr(e)}
 
@@ -343,23 +343,49 @@ def main():
                 step()
             pose[0] = rank
         if ex is not None and banded and not args.no_balance and not c5:
-            # set-up, not steps: the stripes dealt again by what they cost under THIS camera.  Every rank knows the times of its own tiles;
-            # summed per stripe and all-reduced they are the same vector on every rank, and the deterministic rule gives every rank the
-            # same table.  Every rank keeps its number of stripes: slabs, chunks and bands keep their sizes.
+            # set-up, not steps: the stripes dealt again by what they cost under THIS camera -- and the new deal KEPT only if the slowest
+            # rank got faster.  Every rank knows the times of its own tiles; summed per stripe and all-reduced they are the same vector
+            # on every rank, and the deterministic rule gives every rank the same table.  Every rank keeps its number of stripes: slabs,
+            # chunks and bands keep their sizes.  (Per-tile times are not the whole story -- a rank's frame is also its schedule's tail:
+            # emulated, the new deal gains 5-6 % at the top-down camera and 0-2 % at the default one, where it lost 2 % once.)
+            def slowest_rank_period(n=12):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(n):
+                    t.render(stream)
+                torch.cuda.synchronize()
+                x = torch.tensor([(time.perf_counter() - c0) / n * 1e3], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+                return float(x.item())
+
+            round_robin = vdist.layout_code(0, vdist.layout_stripe_log2(ex.skew))
+            if ex.skew != round_robin:                               # (a deal made for another camera: start from the plain one)
+                flush()
+                ex.set_layout(round_robin); t.set_tile_shard(rank, world, round_robin)
+                for _ in range(SETTLE):
+                    t.render(stream)
             sl2 = vdist.layout_stripe_log2(ex.skew)
             nstripes = ((W + 63) // 64) >> sl2
             mine = vdist.stripe_times(t.tile_times(), vdist.tile_layout(W, H, rank, world, ex.skew), nstripes, sl2)
             x = torch.from_numpy(mine).to("cpu" if args.rehearse else dev)
             dist.all_reduce(x, op=dist.ReduceOp.SUM)
-            word = vdist.balanced_layout(x.cpu().numpy(), world, sl2)
-            balance_info.update({"stripe_ms": [round(float(v), 4) for v in x.cpu().numpy()], "camera": camera,
-                                 "owner": [int(o) for o in cabi.balance_stripes(x.cpu().numpy(), world)]})
-            if word != ex.skew:
+            stripe_ms = x.cpu().numpy()
+            word = vdist.balanced_layout(stripe_ms, world, sl2)
+            balance_info.clear()
+            balance_info.update({"camera": camera, "stripe_ms": [round(float(v), 4) for v in stripe_ms], "owner": [int(o) for o in cabi.balance_stripes(stripe_ms, world)],
+                                 "kept": False})
+            if word != round_robin:
+                before = slowest_rank_period()
                 flush()
-                ex.set_layout(word)
-                t.set_tile_shard(rank, world, word)
+                ex.set_layout(word); t.set_tile_shard(rank, world, word)
                 for _ in range(SETTLE):
                     t.render(stream)
+                after = slowest_rank_period()
+                balance_info.update({"slowest_rank_ms_round_robin": before, "slowest_rank_ms_dealt_by_times": after, "kept": after < 0.995 * before})
+                if not balance_info["kept"]:                         # (every rank holds the same two numbers: the same decision everywhere)
+                    ex.set_layout(round_robin); t.set_tile_shard(rank, world, round_robin)
+                    for _ in range(SETTLE):
+                        t.render(stream)
         if ex is not None and not exchanged[0]:
             # set-up, not steps: the first exchange creates the point-to-point channels (RCCL opens them lazily, about a second);
             # like communicator creation it must not land in the timed region when the caller asks for --warmup 0
@@ -626,7 +652,7 @@ def main():
             workload = f"C4: Scene {W}x{H}, grid={G}, R32F {G}x{G} heightmap rng(20250816)*0.5-0.25, {args.camera} camera, viridis"
             par = ("1 GPU, whole frame" if world == 1 else
                    f"64x64 screen tiles in column stripes of {1 << vdist.layout_stripe_log2(ex.skew)} tile(s) over {world} GPUs (" +
-                   ("stripes dealt by their measured times, the same number to every rank: vf_balance_stripes" if balance_info else
+                   ("stripes dealt by their measured times, the same number to every rank: vf_balance_stripes" if ex.skew & (1 << 20) else
                     f"owner = ((tx >> {vdist.layout_stripe_log2(ex.skew)}) + {ex.skew & 0xFFFF}*ty) % {world}") + "), " +
                    ("all-to-all (RCCL through the C-ABI, vf_dist_exchange_bands) + one band stitched per rank + bands gathered in place on rank 0, " if cabi_bands else
                     "all-to-all (RCCL via torch.distributed) + one band stitched per rank + bands gathered in place on rank 0, " if banded else
