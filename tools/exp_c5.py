@@ -13,11 +13,19 @@ h = np.random.default_rng(20250817).random((G, G), dtype=np.float32) * np.float3
 t = cabi.Terrain(W, H, G, vf.colormap_rgba8("viridis")); t.set_height(h)
 if len(sys.argv) > 2: t.set_raster_groups(int(sys.argv[2]))
 us = np.stack([b.orbit_uniforms(k, W, H) for k in range(64)])
-t.render_batch(us[:24]); t.sync()
+outs = None
+if os.environ.get("VF_C5_BUFFERS"):                      # poses into N buffers of their own in turn: with three plan states a batch overlaps consecutive poses
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7"); hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    bufs = []
+    for _ in range(int(os.environ["VF_C5_BUFFERS"])):
+        p = C.c_void_p(); assert hip.hipMalloc(C.byref(p), 2048 * 1088 * 4) == 0; bufs.append(p.value)
+    outs = [bufs[k % len(bufs)] for k in range(64)]
+t.render_batch(us[:24], outs[:24] if outs else None); t.sync()
 laps = []
 for lap in range(3):
     t.enable_timing(True, stats=False)
-    t0 = time.perf_counter(); t.render_batch(us); t.sync(); laps.append((time.perf_counter() - t0) / 64 * 1e3)
+    t0 = time.perf_counter(); t.render_batch(us, outs); t.sync(); laps.append((time.perf_counter() - t0) / 64 * 1e3)
     tile, period = t.frame_times(); t.enable_timing(False)
 if os.environ.get("VF_C5_STATIC"):
     for k in (0, 4, 8, 12):
