@@ -442,6 +442,52 @@ def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
         t.close()
 
 
+def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, oracle, luts):
+    """Round 5: a caller that waits for every frame of a camera at rest gets the NEXT frame's plan queued behind each frame
+    (vf_hip.hip::render_impl).  Whatever changes between two frames -- camera, heights, exaggeration, shade mode, shard, timing -- the plan
+    made ahead is for other inputs and must be thrown away: every frame below equals the oracle's."""
+    W, H, G = 640, 400, 192
+    h0, h1 = heightmap(41, G), heightmap(42, G)
+    cams = [DEFAULT_CAMERA, ((2.5, 1.6, -2.8), (0.1, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.1, 100.0), FILL_CAMERA]
+    t = cabi.Terrain(W, H, G, luts["viridis"])
+    try:
+        t.set_shade_precision(0)
+        t.set_height(h0)
+
+        def settle_and_check(u, h, what, **kw):
+            for _ in range(5):                                   # synchronous frames of one set of inputs: from the fourth on the plan comes from the call before
+                t.render(); t.sync()
+            ref, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=8, **kw)
+            assert np.array_equal(t.read_rgba(), ref), what
+            return ref_vis
+
+        u = oracle.look_at_uniforms(1, W, H, *cams[0]); t.set_uniforms(u)
+        settle_and_check(u, h0, "at rest")
+        u = oracle.look_at_uniforms(1, W, H, *cams[1]); t.set_uniforms(u)                # a plan for camera 0 is waiting: not this frame's
+        t.render(); t.sync()
+        ref, _ = oracle.render_terrain(u, W, H, G, h0, luts["viridis"], nthreads=8, want_vis=False)
+        assert np.array_equal(t.read_rgba(), ref), "first frame of another camera"
+        settle_and_check(u, h0, "other camera at rest")
+        t.set_height(h1)                                           # other heights under a waiting plan
+        vis = settle_and_check(u, h1, "other heights")
+        assert np.array_equal(t.read_visibility(), vis)           # (a diagnostic re-render in between)
+        u2 = u.copy(); u2[38] = np.float32(1.7); t.set_uniforms(u2)                     # exaggeration: same camera matrices, other geometry
+        settle_and_check(u2, h1, "exaggeration")
+        t.enable_timing(True); t.render(); t.sync(); assert t.timings()["frames"] >= 1; t.enable_timing(False)     # timing switched on over a waiting plan
+        ref, _ = oracle.render_terrain(u2, W, H, G, h1, luts["viridis"], nthreads=8, want_vis=False)
+        assert np.array_equal(t.read_rgba(), ref), "timed frame"
+        t.set_shard(1, 2, 64)                                      # a shard under a waiting plan
+        for _ in range(4):
+            t.render(); t.sync()
+        rows = np.flatnonzero(((np.arange(H) // 64) % 2) == 1)
+        assert np.array_equal(t.read_rgba(), ref[rows]), "band shard"
+        t.set_shard(0, 1, 64)
+        u3 = oracle.look_at_uniforms(1, W, H, *cams[2]); t.set_uniforms(u3)
+        settle_and_check(u3, h1, "top-down camera")
+    finally:
+        t.close()
+
+
 def test_orbiting_camera_back_to_back(cabi, oracle, luts):
     """A camera that moves the picture by more than a tile per frame makes the plan wait for the previous frame's feedback
     instead of overlapping it (vf_hip.hip: kFreshFeedbackPx); slow motion keeps the overlap.  Frames are queued back to back

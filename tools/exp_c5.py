@@ -28,7 +28,7 @@ for lap in range(3):
     t0 = time.perf_counter(); t.render_batch(us, outs); t.sync(); laps.append((time.perf_counter() - t0) / 64 * 1e3)
     tile, period = t.frame_times(); t.enable_timing(False)
 if os.environ.get("VF_C5_STATIC"):
-    for k in (0, 4, 8, 12):
+    for k in [int(v) for v in os.environ.get("VF_C5_STATIC_POSES", "0,4,8,12").split(",")]:
         t.set_uniforms(us[k])
         for _ in range(40): t.render()
         t.sync(); t0 = time.perf_counter()

@@ -118,6 +118,14 @@ struct vf_ctx {
     uint64_t maps_uploaded = 0;  // bit k: map k is there
 };
 
+// What the second half of a frame (draw_frame) needs of the first (plan_frame)
+struct FramePlan {
+    FrameParams P;
+    uint32_t set = 0, ntiles = 0, ev_slot = 0;
+    bool solo = false, motion_starts = false, timed = false;     // timed: the plan's three timing events were recorded, in ring slot ev_slot
+    uint32_t *rc_lo = nullptr, *rc_hi = nullptr, *seg_count = nullptr;
+};
+
 struct vf_terrain {
     vf_ctx *ctx = nullptr;
     uint32_t W = 0, H = 0, n = 0;
@@ -196,6 +204,24 @@ struct vf_terrain {
     uint32_t big_reads = 0;                       // frame-sized read-backs so far (the pinned ring / buffers are made by the second)
     uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
     hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    // THE NEXT FRAME'S PLAN, QUEUED AHEAD (round 5).  A camera at rest draws the same plan again and again, and a caller that waits for
+    // each frame (render_png, render_rgba: every call of the reference's API) used to pay the plan chain -- block boxes, set-up pass,
+    // plan, sort: 0.2 ms at C4 -- in front of every tile kernel, because nothing is left to hide it under once the caller has waited.
+    // So when a frame was drawn with the very inputs of the frame before it, the first half of the NEXT frame (plan_frame) is queued
+    // right behind it: by the time the caller comes back the plan is there.  `inputs_gen` counts everything a plan depends on (uniforms,
+    // heights, shard, shade mode, timing); a plan made ahead is used only for the generation it was made for, and otherwise thrown
+    // away: the bookkeeping it advanced is rolled back and the frame is planned again (its kernels queue behind the stale ones).
+    uint64_t inputs_gen = 1;
+    struct PrePlan {
+        bool valid = false;
+        FramePlan K;
+        uint64_t gen = 0;
+        // what plan_frame advanced (restored when the plan is thrown away)
+        uint32_t cur_set = 0, frame_no = 0, frames_since_reset = 0;
+        bool camera_moving = false, was_moving = false, have_drawn = false;
+        float u_drawn[32] = {};
+    } pre;
+    uint64_t last_drawn_gen = 0;         // inputs_gen of the frame drawn last (two frames of one generation: the camera is at rest)
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     uint8_t *d_stripe_owner = nullptr;   // tile shards with a registered stripe map: owner per column stripe (kMaxStripes bytes)
     bool use_map = false;
@@ -376,6 +402,19 @@ static hipError_t sync_sides(const vf_terrain *t)            // (the side stream
     return e;
 }
 
+// A plan queued ahead of its frame (vf_terrain::pre) is thrown away: back to where the handle stood before it, and that set's segment list
+// starts empty again (the stale k_block_boxes filled it; its k_clear, which would have emptied it, never runs).
+static hipError_t drop_preplan(vf_terrain *t)
+{
+    if (!t->pre.valid) return hipSuccess;
+    const vf_terrain::PrePlan &R = t->pre;
+    t->pre.valid = false;
+    t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
+    t->camera_moving = R.camera_moving; t->was_moving = R.was_moving; t->have_drawn = R.have_drawn;
+    std::memcpy(t->u_drawn, R.u_drawn, sizeof t->u_drawn);
+    return t->side ? hipMemsetAsync(R.K.seg_count, 0, sizeof(uint32_t), t->side) : hipSuccess;
+}
+
 // A plan state's buffers and events, made when the state is first used (frame 0: at construction; frame 1: by that frame).
 static hipError_t ensure_plan_state(vf_terrain *t, uint32_t k, hipStream_t zero_on)
 {
@@ -521,6 +560,7 @@ void vf_terrain_destroy(vf_terrain *t)
 int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44])
 {
     if (!t || !uniforms) return fail(VF_ERR_INVALID, "NULL argument");
+    if (!t->have_uniforms || std::memcmp(t->u, uniforms, sizeof t->u) != 0) t->inputs_gen++;     // (a plan made ahead was made for the old block)
     std::memcpy(t->u, uniforms, sizeof t->u);
     t->have_uniforms = true;
     return VF_OK;
@@ -528,6 +568,8 @@ int vf_terrain_set_uniforms(vf_terrain *t, const float uniforms[44])
 
 static int set_height_common(vf_terrain *t, uint32_t tw, uint32_t th)
 {
+    t->inputs_gen++;
+    VF_HIP_TRY(drop_preplan(t));
     t->g_epoch_frames = 0; t->g_epoch_id++; t->g_n[0] = t->g_n[1] = 0;     // other heights: which line loop is faster is measured again
     bool resized = tw != t->tw || th != t->th;
     t->tw = tw; t->th = th;
@@ -586,6 +628,7 @@ int vf_terrain_set_shade_mode(vf_terrain *t, int mode)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (mode != VF_SHADE_REFERENCE && mode != VF_SHADE_SPEC_T32) return fail(VF_ERR_INVALID, "unknown shade mode");
+    if (t->shade_mode != (uint32_t)mode) t->inputs_gen++;
     t->shade_mode = (uint32_t)mode;
     return VF_OK;
 }
@@ -594,6 +637,7 @@ int vf_terrain_set_shade_precision(vf_terrain *t, int precision)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
     if (precision != VF_PRECISION_EXACT && precision != VF_PRECISION_FAST) return fail(VF_ERR_INVALID, "unknown shade precision");
+    if (t->precision != (uint32_t)precision) t->inputs_gen++;
     t->precision = (uint32_t)precision;
     return VF_OK;
 }
@@ -622,6 +666,8 @@ int vf_terrain_set_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uint32_t
     if (!is_pow2(band_h) || band_h < (uint32_t)kTileH) return fail(VF_ERR_INVALID, "band_h must be a power of two >= 64 (the tile height)");
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     VF_HIP_TRY(hipStreamSynchronize(t->last_stream ? t->last_stream : t->ctx->stream));
+    t->inputs_gen++;
+    VF_HIP_TRY(drop_preplan(t));
     t->rank = rank; t->nranks = nranks; t->band_h = band_h;
     t->shard_tiles = false; t->use_map = false;
     t->local_rows = compute_local_rows(t->H, rank, nranks, band_h);
@@ -760,6 +806,8 @@ int vf_terrain_set_tile_shard(vf_terrain *t, uint32_t rank, uint32_t nranks, uin
     if (sm) VF_HIP_TRY(hipMemcpy(t->d_stripe_owner, sm->owner.data(), sm->owner.size(), hipMemcpyHostToDevice));
     t->use_map = sm != nullptr;
     if (n) VF_HIP_TRY(hipMemcpy(t->d_tile_map, map.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    t->inputs_gen++;
+    VF_HIP_TRY(drop_preplan(t));
     t->shard_tiles = true; t->local_tiles = n;
     t->rank = rank; t->nranks = nranks; t->skew = skew;
     t->local_rows = 0;                                   // row-oriented accessors do not apply to a tile-major buffer
@@ -922,9 +970,13 @@ constexpr float kFreshFeedbackPx = 24.0f;   // from here on (3/8 of a tile per f
 // the fast fragment path exists for fs_main as coded; the documented-only SPEC_T32 stage always takes the exact arithmetic
 static bool fast_shading(const vf_terrain *t) { return t->precision == VF_PRECISION_FAST && t->shade_mode == VF_SHADE_REFERENCE; }
 
-static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
+// A frame in two halves (round 5).  plan_frame: everything up to the plan's last kernel -- block boxes, set-up pass, plan, sort -- on the
+// side streams (a handle's first frame: on `s`); it touches plan state only.  draw_frame: the kernels on the caller's stream.  What the
+// second half needs of the first travels in a FramePlan, so that the first half of the NEXT frame can be queued ahead of its call
+// (vf_terrain::pre, render_impl).
+static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
 {
-    FrameParams P;
+    FrameParams &P = K.P;
     build_params(t, P);
     AxisTables A = axis(t);
     const uint32_t ntiles = t->local_tiles;
@@ -982,7 +1034,9 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
     hipStream_t side = solo ? s : t->side, side2 = solo ? s : t->side2;
-    hipEvent_t *ev = t->ev[t->timed_frames % vf_terrain::kTimingRing];
+    K.ev_slot = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
+    K.timed = t->timing;
+    hipEvent_t *ev = t->ev[K.ev_slot];
     // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
     VF_HIP_TRY(hipStreamWaitEvent(side, S.drawn, 0));
     if (t->bounds_dirty) {
@@ -1039,6 +1093,23 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     VF_HIP_TRY(hipGetLastError());                              // a failed plan launch is reported here: the probe block below clears hipEventQuery's "not ready"
     if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));
+    K.set = set; K.ntiles = ntiles; K.solo = solo; K.motion_starts = motion_starts; K.rc_lo = rc_lo; K.rc_hi = rc_hi; K.seg_count = seg_count;
+    return VF_OK;
+}
+
+static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool write_vis)
+{
+    const FrameParams &P = K.P;
+    vf_terrain::PlanState &S = t->ps[K.set];
+    const uint32_t ntiles = K.ntiles, set = K.set;
+    const bool motion_starts = K.motion_starts, solo = K.solo;
+    uint32_t *const rc_lo = K.rc_lo, *const rc_hi = K.rc_hi, *const seg_count = K.seg_count;
+    // (a plan queued ahead of its call may have been made before timing was switched on, or for another position of the ring: its three
+    //  events are then recorded here -- valid, if not telling -- so that the frame's entry in the ring is complete)
+    const uint32_t slot_now = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
+    hipEvent_t *ev = t->ev[slot_now];
+    if (t->timing && (!K.timed || K.ev_slot != slot_now)) for (int k = 0; k < 3; ++k) VF_HIP_TRY(hipEventRecord(ev[k], s));
+    (void)solo;
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
     uint32_t *stats = t->timing && t->stats_on ? t->d_stats : nullptr;
     const uint32_t nstats = (uint32_t)(4 + 4 * ((size_t)t->ntx * t->nty + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32);   // zeroed by k_clear (no memset dispatch)
@@ -1151,6 +1222,40 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     return VF_OK;
 }
 
+static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
+{
+    FramePlan K;
+    bool planned = false;
+    // Was the GPU done with the previous frame when this call came in?  Then the caller waits between frames (render_png, render_rgba,
+    // anything that reads a frame back) and the next frame's plan is worth queuing ahead; a caller that streams frames brings the next
+    // plan itself, at the same moment, and a plan queued ahead would only be one more after the last frame.
+    const bool idle_at_entry = t->rendered && hipEventQuery(t->ps[t->last_set].drawn) == hipSuccess;
+    (void)hipGetLastError();                                // ("not ready" is not an error)
+    if (t->pre.valid) {
+        t->pre.valid = false;
+        if (t->pre.gen == t->inputs_gen && !write_vis) { K = t->pre.K; planned = true; }
+        else { t->pre.valid = true; VF_HIP_TRY(drop_preplan(t)); }     // made for other inputs
+    }
+    if (!planned) { const int rc = plan_frame(t, s, K); if (rc != VF_OK) return rc; }
+    const bool again = t->last_drawn_gen == t->inputs_gen;      // the frame before this one was drawn from the same inputs
+    const int rc = draw_frame(t, s, K, write_vis);
+    if (rc != VF_OK) return rc;
+    t->last_drawn_gen = t->inputs_gen;
+    // the camera is at rest (two frames from one set of inputs), the handle is past its first frames, nothing diagnostic is going on:
+    // the next frame's plan goes out now
+    if (again && idle_at_entry && !write_vis && t->side && !t->bounds_dirty && !t->camera_moving && !t->was_moving && t->frames_since_reset > vf_terrain::kPlanStates && !(t->timing && t->stats_on)) {
+        vf_terrain::PrePlan &R = t->pre;
+        R.cur_set = t->cur_set; R.frame_no = t->frame_no; R.frames_since_reset = t->frames_since_reset;
+        R.camera_moving = t->camera_moving; R.was_moving = t->was_moving; R.have_drawn = t->have_drawn;
+        std::memcpy(R.u_drawn, t->u_drawn, sizeof R.u_drawn);
+        if (plan_frame(t, s, R.K) == VF_OK) { R.valid = true; R.gen = t->inputs_gen; }
+        else {                                              // (a failed launch: the next call plans for itself and reports it)
+            t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
+        }
+    }
+    return VF_OK;
+}
+
 int vf_terrain_render(vf_terrain *t, void *stream)
 {
     if (!t) return fail(VF_ERR_INVALID, "NULL argument");
@@ -1169,6 +1274,7 @@ int vf_terrain_render_batch(vf_terrain *t, const float *uniforms, uint32_t n, vo
     hipStream_t s = stream ? (hipStream_t)stream : t->ctx->stream;
     for (uint32_t k = 0; k < n; ++k) {
         if (dev_rgba && !dev_rgba[k]) return fail(VF_ERR_INVALID, "dev_rgba holds a NULL output buffer");
+        if (!t->have_uniforms || std::memcmp(t->u, uniforms + 44u * k, sizeof t->u) != 0) t->inputs_gen++;
         std::memcpy(t->u, uniforms + 44u * k, sizeof t->u);
         t->have_uniforms = true;
         if (dev_rgba) t->d_rgba = (uint32_t *)dev_rgba[k];
