@@ -41,7 +41,17 @@ with tempfile.TemporaryDirectory() as tmp:
     t0 = time.perf_counter(); rgba = b.render_rgba(); out["first_render_rgba"] = ms(t0)
     t0 = time.perf_counter(); rgba2 = b.render_rgba(); out["second_render_rgba"] = ms(t0)
     t0 = time.perf_counter(); rgba3 = b.render_rgba(); out["third_render_rgba"] = ms(t0)
-    t0 = time.perf_counter(); rgba3 = b.render_rgba(); out["fourth_render_rgba"] = ms(t0)
+    t0 = time.perf_counter(); rgba4 = b.render_rgba(); out["fourth_render_rgba"] = ms(t0)
+    # a caller that KEEPS its frames gets page-locked arrays for three of them (9 ms to make each), ordinary ones after that ...
+    kept = [rgba, rgba2, rgba3, rgba4]
+    out["render_rgba_keeping_every_frame"] = []
+    for _ in range(3):
+        t0 = time.perf_counter(); kept.append(b.render_rgba()); out["render_rgba_keeping_every_frame"].append(ms(t0))
+    # ... and one that drops them renders into the pool's buffers again and again
+    del kept, rgba3, rgba4
+    out["render_rgba_dropping_the_frame"] = []
+    for _ in range(3):
+        t0 = time.perf_counter(); f = b.render_rgba(); out["render_rgba_dropping_the_frame"].append(ms(t0)); del f
     out["frames_equal"] = bool(np.array_equal(rgba, rgba2))
     out["covered_fraction"] = float((rgba.reshape(-1, 4) != rgba[0, 0]).any(axis=1).mean())
     t0 = time.perf_counter(); del b; out["destroy"] = ms(t0)

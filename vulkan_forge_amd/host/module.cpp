@@ -102,7 +102,21 @@ public:
         }
         void *p = nullptr;
         check(vf_host_alloc(bytes, &p));
+        { std::lock_guard<std::mutex> lk(mu); made++; }
         return p;
+    }
+    // ... for a caller that can do without: nullptr once kMaxMade buffers are out with arrays the caller keeps -- page-locking a C4
+    // frame costs 9 ms, an ordinary array 3 ms more than a pooled one, so a loop that keeps every frame stops paying for buffers it
+    // never returns (profiles/r05_one_shot.json: 11-13 ms per call before, 5 after the second)
+    void *take_or_null(size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            bool have = false;
+            for (auto &b : idle) have |= b.second == bytes;
+            if (!have && made >= kMaxMade) return nullptr;
+        }
+        return take(bytes);
     }
     void give(void *p, size_t bytes)
     {
@@ -112,12 +126,13 @@ public:
             idle.emplace_back(p, bytes);
             size_t held = 0;
             for (auto &b : idle) held += b.second;
-            while (idle.size() > kMaxIdle || held > kMaxIdleBytes) { held -= idle.front().second; drop.push_back(idle.front().first); idle.erase(idle.begin()); }
+            while (idle.size() > kMaxIdle || held > kMaxIdleBytes) { held -= idle.front().second; drop.push_back(idle.front().first); idle.erase(idle.begin()); made--; }
         }
         for (void *d : drop) vf_host_free(d);
     }
 private:
-    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30;
+    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30, kMaxMade = 3;
+    size_t made = 0;                                            // buffers page-locked and not freed: idle ones + those out with arrays
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> idle;
 };
@@ -271,7 +286,12 @@ public:
             return a;
         }
         // frame-sized: the array lives in page-locked memory from the pool (above) -- one DMA transfer, no host copy
-        void *p = PinnedPool::get().take(bytes);
+        void *p = PinnedPool::get().take_or_null(bytes);
+        if (!p) {                                                // (the caller keeps its frames: ordinary arrays from here on)
+            py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
+            render_into(a.mutable_data(), rows);
+            return a;
+        }
         py::capsule owner = pinned_owner(p, bytes);             // (returns the buffer if anything below throws)
         render_into(static_cast<uint8_t *>(p), rows);
         return py::array_t<uint8_t>({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 }, static_cast<uint8_t *>(p), owner);
