@@ -214,7 +214,9 @@ int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows
 /* Page-locked host memory for read-back destinations (new; the reference maps a fresh staging buffer per call,
  * src/terrain/mod.rs:446-451).  vf_terrain_read_rgba into such a buffer is ONE DMA transfer (C4: 64 MiB in 1.2 ms); into ordinary
  * pageable memory it goes through the handle's ring of pinned chunks and a copy by host threads, and a frame-sized fresh
- * destination is page-fault bound (2-5 ms).  Any hipHostMalloc / hipHostRegister memory of the caller's is recognised as well. */
+ * destination is page-fault bound (2-5 ms).  Any hipHostMalloc / hipHostRegister memory of the caller's is recognised as well.
+ * Buffers of 4 MiB and more are 2 MiB-aligned MADV_HUGEPAGE memory registered with the runtime (2.6 ms to make for 64 MiB, where
+ * hipHostMalloc takes 9 and its first copy another 11-16); free them with vf_host_free only. */
 int vf_host_alloc(size_t bytes, void **host);
 void vf_host_free(void *host);
 /* Read-back for render_png (src/terrain/mod.rs:439-490): the last frame as PNG scanlines -- per row one filter-type byte

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <thread>
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <rccl/rccl.h>     // types only: the functions are resolved at run time (resolve_rccl)
 
 using namespace vf;
@@ -103,6 +104,51 @@ uint32_t ilog2(uint32_t v)
 }
 
 } // namespace
+
+// Page-locked host memory.  hipHostMalloc takes 7-9 ms for a C4 frame (64 MiB), the first copy into it another 11-16, hipHostFree 5:
+// the runtime faults the buffer in 4 KiB page by page.  The same bytes as 2 MiB-aligned ordinary memory with MADV_HUGEPAGE, then
+// hipHostRegister: 2.5-2.8 ms to make, copies at full rate (1.19 ms) from the first one, 2.5 ms to free (tools/micro/pin_cost.hip,
+// round 5) -- cheaper than the page faults of ONE copy into fresh ordinary memory (4.4-4.9 ms), so even a one-shot caller's only
+// read-back goes into such a buffer.  Small buffers and hosts without huge pages: hipHostMalloc.
+struct PinnedRegistry {
+    std::mutex mu;
+    std::vector<void *> registered;                            // made by pinned_alloc's huge-page branch (freed by unregister + free)
+    static PinnedRegistry &get() { static PinnedRegistry *r = new PinnedRegistry; return *r; }
+};
+static hipError_t pinned_alloc(void **out, size_t n)
+{
+    constexpr size_t kHuge = (size_t)2 << 20;
+    *out = nullptr;
+    if (n >= 2 * kHuge) {
+        void *p = nullptr;
+        const size_t r = (n + kHuge - 1) & ~(kHuge - 1);
+        if (posix_memalign(&p, kHuge, r) == 0) {
+            (void)madvise(p, r, MADV_HUGEPAGE);                 // (refused or unavailable: ordinary pages, still correct)
+            if (hipHostRegister(p, r, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(PinnedRegistry::get().mu);
+                PinnedRegistry::get().registered.push_back(p);
+                *out = p;
+                return hipSuccess;
+            }
+            (void)hipGetLastError();
+            std::free(p);
+        }
+    }
+    return hipHostMalloc(out, n, hipHostMallocDefault);
+}
+static void pinned_free(void *p)
+{
+    if (!p) return;
+    bool ours = false;
+    {
+        PinnedRegistry &R = PinnedRegistry::get();
+        std::lock_guard<std::mutex> lk(R.mu);
+        auto it = std::find(R.registered.begin(), R.registered.end(), p);
+        if (it != R.registered.end()) { R.registered.erase(it); ours = true; }
+    }
+    if (ours) { (void)hipHostUnregister(p); std::free(p); }
+    else (void)hipHostFree(p);
+}
 
 struct vf_ctx {
     int device = 0;
@@ -200,8 +246,6 @@ struct vf_terrain {
     float *d_lut = nullptr;              // 256*3 linear floats
     uint32_t *d_rgba_own = nullptr;
     uint8_t *d_png = nullptr, *h_png = nullptr;   // PNG scanlines of the last frame: device, pinned host
-    uint8_t *h_png_first = nullptr;               // ... and ordinary host memory for the handle's FIRST read-back (page-locking 64 MiB costs 9 ms: more than it saves once)
-    uint32_t big_reads = 0;                       // frame-sized read-backs so far (the pinned ring / buffers are made by the second)
     uint8_t *h_stage = nullptr;                   // kStageSlots x kStageChunk pinned bytes: device -> pageable host copies go through here
     hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     // THE NEXT FRAME'S PLAN, QUEUED AHEAD (round 5).  A camera at rest draws the same plan again and again, and a caller that waits for
@@ -546,11 +590,10 @@ void vf_terrain_destroy(vf_terrain *t)
         if (S.set_up) (void)hipEventDestroy(S.set_up);
     }
     // (side / side2 / copy_stream belong to the context)
-    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    pinned_free(t->h_stage);
     for (auto &e : t->stage_ev) if (e) (void)hipEventDestroy(e);
     if (t->d_png) (void)hipFree(t->d_png);
-    if (t->h_png) (void)hipHostFree(t->h_png);
-    if (t->h_png_first) std::free(t->h_png_first);
+    pinned_free(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
     for (auto &g : t->gprobe) { if (g.a) (void)hipEventDestroy(g.a); if (g.b) (void)hipEventDestroy(g.b); }
@@ -1392,10 +1435,8 @@ static bool is_pinned_host(const void *p)
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
     // a destination in pinned host memory (vf_host_alloc, or the caller's own hipHostMalloc / hipHostRegister): one DMA, nothing to stage
-    // ... and a handle's FIRST frame-sized read-back goes through the runtime's own staging (5 ms for 64 MiB): the ring below costs 4 ms to
-    // page-lock and pays off from the second read on -- the reference's usage is construct, render once (src/terrain/mod.rs:410-491)
-    if (n < kStageChunk || is_pinned_host(dst) || (!t->h_stage && t->big_reads++ == 0)) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
-    if (!t->h_stage) VF_HIP_TRY(hipHostMalloc(&t->h_stage, kStageSlots * kStageChunk, hipHostMallocDefault));
+    if (n < kStageChunk || is_pinned_host(dst)) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
+    if (!t->h_stage) VF_HIP_TRY(pinned_alloc((void **)&t->h_stage, kStageSlots * kStageChunk));
     for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
     const unsigned nthreads = copy_threads();
@@ -1455,11 +1496,11 @@ int vf_host_alloc(size_t bytes, void **host)
 {
     if (!host || bytes == 0) return fail(VF_ERR_INVALID, "NULL argument or zero size");
     *host = nullptr;
-    hipError_t e = hipHostMalloc(host, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { *host = nullptr; return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    hipError_t e = pinned_alloc(host, bytes);
+    if (e != hipSuccess) { *host = nullptr; return fail(e == hipErrorOutOfMemory ? VF_ERR_NOMEM : VF_ERR_HIP, std::string("page-locked allocation: ") + hipGetErrorString(e)); }
     return VF_OK;
 }
-void vf_host_free(void *host) { if (host) (void)hipHostFree(host); }
+void vf_host_free(void *host) { pinned_free(host); }
 
 int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines, size_t *nbytes)
 {
@@ -1472,18 +1513,10 @@ int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines,
     hipStream_t s = t->last_stream ? t->last_stream : t->ctx->stream;
     hipLaunchKernelGGL(k_png_filter, dim3(t->H), dim3(256), 0, s, (const uint32_t *)t->d_rgba, t->W, t->d_png);
     VF_HIP_TRY(hipGetLastError());
-    // the handle's first read-back lands in ordinary memory (the runtime stages it); the page-locked buffer -- 9 ms to make for a C4
-    // frame, then one DMA per frame -- is made by the second: persistent, where the reference allocates per call (:446-451)
-    uint8_t *host = nullptr;
-    if (!t->h_png && t->big_reads++ == 0 && n >= kStageChunk) {
-        if (!t->h_png_first) t->h_png_first = (uint8_t *)std::malloc(n);
-        if (!t->h_png_first) return fail(VF_ERR_NOMEM, "out of host memory");
-        host = t->h_png_first;
-    } else {
-        if (!t->h_png) VF_HIP_TRY(hipHostMalloc(&t->h_png, n, hipHostMallocDefault));
-        if (t->h_png_first) { std::free(t->h_png_first); t->h_png_first = nullptr; }
-        host = t->h_png;
-    }
+    // the scanlines land in a page-locked buffer of the handle (pinned_alloc: 2.6 ms to make for a C4 frame, then one DMA per frame):
+    // persistent, where the reference allocates per call (:446-451)
+    if (!t->h_png) VF_HIP_TRY(pinned_alloc((void **)&t->h_png, n));
+    uint8_t *host = t->h_png;
     VF_HIP_TRY(hipMemcpyAsync(host, t->d_png, n, hipMemcpyDeviceToHost, s));
     VF_HIP_TRY(hipStreamSynchronize(s));
     *host_scanlines = host;

@@ -89,7 +89,8 @@ vf_ctx *global_ctx()
 // render_rgba returns a NumPy array OVER such a buffer instead of copying the frame into fresh pageable memory: the device writes it
 // with one DMA transfer (C4: 64 MiB in 1.2 ms) where the staged copy into untouched pages was page-fault bound (2-5 ms; the
 // reference maps a fresh buffer per call, src/terrain/mod.rs:446-451).  The array owns its buffer through a capsule; when the array
-// dies the buffer goes back to the pool, so a render loop alternates between two buffers and never allocates again.
+// dies the buffer goes back to the pool, so a render loop alternates between two buffers and never allocates again.  A buffer is
+// 2 MiB-aligned huge-page memory registered with the runtime (vf_host_alloc): 2.6 ms to make for a C4 frame, where hipHostMalloc took 9.
 class PinnedPool {
 public:
     static PinnedPool &get() { static PinnedPool *p = new PinnedPool; return *p; }   // (process lifetime: never destroyed, like the context)
@@ -102,19 +103,18 @@ public:
         }
         void *p = nullptr;
         check(vf_host_alloc(bytes, &p));
-        { std::lock_guard<std::mutex> lk(mu); made++; }
+        { std::lock_guard<std::mutex> lk(mu); made_bytes += bytes; }
         return p;
     }
-    // ... for a caller that can do without: nullptr once kMaxMade buffers are out with arrays the caller keeps -- page-locking a C4
-    // frame costs 9 ms, an ordinary array 3 ms more than a pooled one, so a loop that keeps every frame stops paying for buffers it
-    // never returns (profiles/r05_one_shot.json: 11-13 ms per call before, 5 after the second)
+    // ... for a caller that can do without: nullptr once kMaxOutBytes of page-locked memory are out with arrays the caller keeps
+    // (page-locked memory cannot be swapped: a loop that keeps every frame gets ordinary arrays beyond that)
     void *take_or_null(size_t bytes)
     {
         {
             std::lock_guard<std::mutex> lk(mu);
             bool have = false;
             for (auto &b : idle) have |= b.second == bytes;
-            if (!have && made >= kMaxMade) return nullptr;
+            if (!have && made_bytes + bytes > kMaxOutBytes) return nullptr;
         }
         return take(bytes);
     }
@@ -126,13 +126,13 @@ public:
             idle.emplace_back(p, bytes);
             size_t held = 0;
             for (auto &b : idle) held += b.second;
-            while (idle.size() > kMaxIdle || held > kMaxIdleBytes) { held -= idle.front().second; drop.push_back(idle.front().first); idle.erase(idle.begin()); made--; }
+            while (idle.size() > kMaxIdle || held > kMaxIdleBytes) { held -= idle.front().second; made_bytes -= idle.front().second; drop.push_back(idle.front().first); idle.erase(idle.begin()); }
         }
         for (void *d : drop) vf_host_free(d);
     }
 private:
-    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30, kMaxMade = 3;
-    size_t made = 0;                                            // buffers page-locked and not freed: idle ones + those out with arrays
+    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30, kMaxOutBytes = (size_t)4 << 30;
+    size_t made_bytes = 0;                                      // page-locked and not freed: idle buffers + those out with arrays
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> idle;
 };
@@ -278,9 +278,10 @@ public:
         uint32_t rows = 0;
         check(vf_terrain_local_rows(t, &rows));
         const size_t bytes = (size_t)rows * W * 4;
-        // small frames, and an object's FIRST frame (page-locking a C4 frame costs 9 ms, more than it saves once: the reference's usage is
-        // construct, render once): an ordinary array
-        if (bytes < ((size_t)4 << 20) || rgba_calls++ == 0 || std::getenv("VF_RGBA_PAGEABLE")) {
+        // small frames: an ordinary array.  (Round 5 kept an object's FIRST frame-sized result in ordinary memory too, when page-locking
+        // a C4 frame cost 9 ms; huge pages + registration make the buffer in 2.6 ms, less than the page faults of one copy into fresh
+        // memory -- vf_host_alloc, tools/micro/pin_cost.hip.)
+        if (bytes < ((size_t)4 << 20) || std::getenv("VF_RGBA_PAGEABLE")) {
             py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
             render_into(a.mutable_data(), rows);
             return a;
@@ -399,7 +400,6 @@ private:
         check(vf_terrain_set_uniforms(t, last.data()));
     }
     uint32_t W, H, n = 128;
-    uint32_t rgba_calls = 0;
     vf_terrain *t = nullptr;
     Globals globals;
     Mat4 view{}, proj{};
