@@ -2530,6 +2530,17 @@ __global__ __launch_bounds__(256) void k_png_filter(const uint32_t *__restrict__
     }
 }
 
+// Device -> page-locked host memory by stores (16 bytes per lane, whole 64-byte lines per quarter wave), for read-backs whose
+// destination the device can address (vf_host_alloc / hipHostRegister memory): the copy engine's first transfer of a process costs
+// 8-10 ms on this runtime, a kernel's stores cost the PCIe time only (round 5, tools/exp_second_call.py).  n16: 16-byte words.
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, size_t nbytes)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t k = (size_t)blockIdx.x * 256u + threadIdx.x; k < n16; k += stride) dst[k] = src[k];
+    if (blockIdx.x == 0 && threadIdx.x < (nbytes & 15u))
+        reinterpret_cast<uint8_t *>(dst)[n16 * 16u + threadIdx.x] = reinterpret_cast<const uint8_t *>(src)[n16 * 16u + threadIdx.x];
+}
+
 // multi-GPU, tile shards: [nranks][stride_tiles][64][64] rank-major gather buffer -> (H, W) image.  Tile (tx, ty) belongs
 // to rank (tx + skew * ty) % nranks; a rank numbers its tiles row-major.  Persistent: a few hundred workgroups walk the screen tiles
 // with a grid stride, 16 bytes per lane where the frame allows it.  Few workgroups on purpose: on rank 0 this copy of the whole frame

@@ -124,14 +124,26 @@ inline std::vector<std::vector<uint8_t>> png_pieces_from_scanlines(const uint8_t
         if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_RLE) != Z_OK) throw std::runtime_error("deflateInit2 failed");
         std::vector<uint8_t> &o = idat[r];
         const bool first = r == 0, last = r + 1 == nruns;
-        o.resize(8 + (first ? 2 : 0) + deflateBound(&zs, (uLong)n) + 16 + (last ? 4 : 0) + 4);
+        // the output starts at a quarter of the input and doubles when deflate fills it: sized for the worst case (deflateBound) the 64
+        // runs of a C4 frame zero-filled and faulted in 67 MB per call -- 8-10 ms of a cold process's first render_png calls (round 5)
+        constexpr size_t kTail = 16;                                       // room kept behind the stream: Adler-32, CRC
+        o.resize(8 + 2 + std::max<size_t>(n / 4, (size_t)1 << 16) + kTail);
         size_t at = 8;                                                     // chunk length + type are filled in below
         if (first) { o[at++] = 0x78; o[at++] = 0x01; }                       // zlib header: deflate, 32 KiB window, fastest
+        const size_t stream_at = at;
         zs.next_in = const_cast<Bytef *>(src); zs.avail_in = (uInt)n;
-        zs.next_out = o.data() + at; zs.avail_out = (uInt)(o.size() - at - 8);
-        const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
-        const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0);
-        at += zs.total_out;
+        zs.next_out = o.data() + at; zs.avail_out = (uInt)(o.size() - at - kTail);
+        bool ok = false;
+        for (;;) {
+            const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) break;
+            if (last ? rc == Z_STREAM_END : (zs.avail_in == 0 && zs.avail_out != 0)) { ok = true; break; }
+            if (zs.avail_out != 0) break;                                  // (no progress with room left: cannot happen)
+            const size_t used = (size_t)(zs.next_out - o.data());
+            o.resize(o.size() * 2);
+            zs.next_out = o.data() + used; zs.avail_out = (uInt)(o.size() - used - kTail);
+        }
+        at = stream_at + zs.total_out;
         deflateEnd(&zs);
         if (!ok) throw std::runtime_error("PNG deflate failed");
         adler[r] = adler32(adler32(0L, Z_NULL, 0), src, (uInt)n);
