@@ -262,6 +262,41 @@ def test_large_readback_goes_through_the_pinned_ring_unchanged(luts, monkeypatch
     assert np.array_equal(part, want[1001:2501])
 
 
+def test_readback_into_page_locked_memory_by_stores_and_by_the_copy_engine(luts):
+    """vf_host_alloc destinations are written by the device's own stores (k_copy_to_host: 16 bytes per lane + a byte tail) when source
+    and destination are 16-byte aligned, by the copy engine otherwise; hipHostMalloc-sized requests (< 4 MiB) come from the runtime,
+    larger ones from huge pages registered with it.  Every byte must arrive either way, and nothing beyond the frame is touched."""
+    import ctypes as C
+    from vulkan_forge_amd import cabi
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    for W, H in ((1001, 1101), (257, 63)):                        # 4 408 404 B (huge pages; a 4-byte tail) / 64 764 B (hipHostMalloc; 12-byte tail)
+        t = cabi.Terrain(W, H, 64, luts["magma"])
+        try:
+            t.set_height((np.random.default_rng(W).random((64, 64), dtype=np.float32) - np.float32(0.5)) * np.float32(0.4))
+            t.set_uniforms(b.camera_uniforms("fill", W, H))
+            t.render(); t.sync()
+            want = t.read_rgba()                                   # ordinary memory: the plain / staged copy
+            assert len(np.unique(want.reshape(-1, 4), axis=0)) > 50
+            n = W * H * 4
+            p = C.c_void_p()
+            t._check(t.lib.vf_host_alloc(C.c_size_t(n + 64), C.byref(p)))
+            try:
+                buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n + 64,))
+                buf[:] = 0xAB
+                t._check(t.lib.vf_terrain_read_rgba(t.t, p, 0, H))                      # aligned both ends: stores
+                assert np.array_equal(buf[:n].reshape(H, W, 4), want) and (buf[n:] == 0xAB).all()
+                buf[:] = 0xCD
+                t._check(t.lib.vf_terrain_read_rgba(t.t, C.c_void_p(p.value + 4), 3, H - 5))   # W odd, y0 = 3: neither end aligned -> copy engine
+                m = W * (H - 5) * 4
+                assert np.array_equal(buf[4:4 + m].reshape(H - 5, W, 4), want[3:H - 2]) and (buf[:4] == 0xCD).all() and (buf[4 + m:] == 0xCD).all()
+            finally:
+                t.lib.vf_host_free(p)
+        finally:
+            t.close()
+
+
 def test_frame_sized_render_rgba_arrays_live_in_the_pinned_pool(oracle, luts, monkeypatch):
     """Round 5: frame-sized render_rgba results are NumPy arrays over page-locked buffers of a pool (one DMA, no host copy); every call
     returns its own array, a dead array's buffer is reused, and the pageable path (VF_RGBA_PAGEABLE) gives the same bytes."""
