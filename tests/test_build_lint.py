@@ -40,7 +40,7 @@ def test_the_tile_kernel_keeps_the_properties_its_build_flags_buy():
     instantiations inside 96 vector registers with next to no scratch traffic (at 128 registers the next frame's
     set-up pass no longer fits beside it, +12 %; a reload per pulled block cost 2-6 %).  A compiler bump that silently loses them fails
     HERE instead of in a benchmark: for k_tile<*, COMPLETE = false, FAST = true, *> -- the launches that draw the frames --
-    VGPRs <= 96, scratch <= 28 bytes per lane, and no scratch access inside the chunk loop or below it (loop depth >= 2: the block
+    VGPRs <= 96, scratch <= 48 bytes per lane (a dozen values parked at kernel entry and reloaded once per work item), and no scratch access inside the chunk loop or below it (loop depth >= 2: the block
     pull loop, pass A / B, the line loop, painting)."""
     import isa_stats                                  # recompiles vf_hip.hip with the build's flags + --save-temps (about 30 s)
     _text, records, depths = isa_stats.collect()
@@ -48,7 +48,7 @@ def test_the_tile_kernel_keeps_the_properties_its_build_flags_buy():
     assert len(mains) == 4, sorted(records)
     for name, nt in mains.items():
         assert int(nt["NumVgprs"]) <= 96, (name, nt)
-        assert int(nt["ScratchSize"]) <= 28, (name, nt)
+        assert int(nt["ScratchSize"]) <= 48, (name, nt)
         assert int(nt["Occupancy"]) >= 5, (name, nt)
         assert int(nt["LDSByteSize"]) <= 81920, (name, nt)       # half a CU's LDS: beyond it the register budget is silently dropped
     assert set(depths) == {"k_tile<false, false, true, true>", "k_tile<false, false, true, false>"}

@@ -457,9 +457,15 @@ struct TileCtx {
     uint32_t *vis;            // LDS, kTileW*kTileH words, skewed (see vis_index)
     const uint32_t *colfin;   // LDS, [64][2]: per tile column, bit r set = pixel (column, r) is final
     const uint32_t *rowfin;   // LDS, [64][2]: per tile row, bit c set
+    const uint32_t *colfin4;  // LDS, [16][2]: the AND of the masks of columns 4 g .. 4 g + 3 (refresh_fin4: rebuilt behind every rescan, may lag, never lies)
+    const uint32_t *rowfin4;  // LDS, [16][2]: ... of rows 4 g .. 4 g + 3
     int32_t px_lo, px_hi;     // inclusive pixel rectangle of the tile, clipped to the target
     int32_t py_lo, py_hi;
 };
+
+#ifndef VF_FIN4
+#define VF_FIN4 1           // the occlusion tests read the four-line masks (refresh_fin4); 0: four line masks per step, as before round 5
+#endif
 
 // LDS layout of the visibility tile: rotate each row by its row number so that a walk down a pixel
 // column visits all 32 banks (plain row-major would keep a column in one bank: 64-word row stride).
@@ -531,9 +537,19 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
     // (one loop header or the other: the body below is shared)
     uint32_t gmask = 0, gleft = 0;
     int32_t passed = 0, nlines_left = 0;
+#if VF_FIN4
+    const int32_t g_first = o_base >> 2, o_skew = o_base & 3;           // (GROUPS) the tile's four-line group of the box's first line, and that line's place in it
+#endif
     if constexpr (GROUPS) {
     // ---- stage 0: the groups of four lines, one per lane and trip; every lane of the triangle takes the same trips ----
+#if VF_FIN4
+    // (groups are the tile's own: lines 4 G .. 4 G + 3 of the tile, G from the one that holds the box's first line -- one load of the
+    //  four-line mask per group; the first and the last group may reach beyond the box: bits of `gmask` stay relative to the first)
+    const int32_t ng = ((o_base + n_outer) >> 2) - g_first + 1;          // at most 17
+    const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
+#else
     const int32_t ng = (n_outer >> 2) + 1;                 // group g = lines 4 g .. min(4 g + 3, n_outer); at most 16
+#endif
     // (a triangle whose lanes have a line or two each gains nothing from the test -- a 4-pixel strip's triangles have four lines in
     //  all: their groups all count as open, and a wave without any other triangle skips the loop)
 #ifndef VF_GROUP_MIN
@@ -546,8 +562,13 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
         const int32_t g = kb + sub;
         bool open = false;
         if (g < ng) {
+#if VF_FIN4
+            const int32_t oa = max(4 * g - o_skew, 0), ob = min(4 * g + 3 - o_skew, n_outer);     // the group's lines inside the box
+            const uint64_t done4 = load_mask(fin4, g_first + g);
+#else
             const int32_t oa = 4 * g, ob = min(oa + 3, n_outer);
             const uint64_t done4 = load_mask(fin, o_base + oa) & load_mask(fin, o_base + min(oa + 1, ob)) & load_mask(fin, o_base + min(oa + 2, ob)) & load_mask(fin, o_base + ob);
+#endif
             int32_t glo, ghi;
             span_group(S, oa, ob, n_inner, glo, ghi);
             if (!S.regular) { glo = 0; ghi = n_inner; }
@@ -567,8 +588,13 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
         int32_t o = idx;
         if constexpr (GROUPS) {
             while (passed < (idx >> 2)) { gleft &= gleft - 1u; ++passed; }
+#if VF_FIN4
+            o = 4 * (int32_t)__builtin_ctz(gleft) + (idx & 3) - o_skew;
+            if (o < 0 || o > n_outer) continue;
+#else
             o = 4 * (int32_t)__builtin_ctz(gleft) + (idx & 3);
             if (o > n_outer) continue;
+#endif
         }
         const uint64_t done = load_mask(fin, o_base + o);
         if constexpr (!GROUPS) { VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;) }
@@ -647,6 +673,7 @@ __device__ __noinline__ void raster_generic(const GVert v[3], float hw, float hh
 // Tile-dependent part of the classification of a primitive k_block_setup found alive (no clipping needed, front-facing, a pixel
 // centre of the target inside its bounding box): does it hold a pixel centre of this tile that is still open?
 // `lines`: how many lines raster_fast will walk for it (the shorter side of its box inside the tile).
+template <bool FOUR>      // FOUR: the occlusion loop reads the four-line masks (the kernel instantiation for wide items; narrow strips keep their lines' own)
 __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, uint32_t &lines VF_RC_ARG)
 {
     const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
@@ -665,6 +692,16 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
 #ifndef VF_CLS_LINES
 #define VF_CLS_LINES 4
 #endif
+    if constexpr (FOUR && VF_FIN4) {
+    // (not in the instantiation for narrow strips: a sliver one or two pixels wide in a 4-pixel strip would answer for the strip's other
+    //  columns as well -- a rank of eight at the default camera +1 %)
+    const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
+    for (int32_t g = o0 >> 2; g <= (o1 >> 2); ++g) {
+        VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_cls++;)
+        if (~load_mask(fin4, g) & seg) return true;
+    }
+    return false;
+    } else {
     for (int32_t o = o0; o <= o1; o += VF_CLS_LINES) {
         VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_cls++;)
         uint64_t all = load_mask(fin, o);
@@ -673,6 +710,7 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
         if (~all & seg) return true;
     }
     return false;
+    }
 }
 
 // ---- fragment stage ---------------------------------------------------------------------------
@@ -906,6 +944,7 @@ __device__ __forceinline__ bool capsule_hits_tile(const float4 &seg, float rad, 
     return capsule_hits_rect(seg, rad, T.px_lo, T.px_hi, T.py_lo, T.py_hi);
 }
 
+template <bool FOUR>
 __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const float4 &cap_seg, float cap_rad, const TileCtx &T)
 {
     if (b.x0 > b.x1) return false;
@@ -918,11 +957,36 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const floa
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
     const int32_t o0 = cols ? x0 - T.px_lo : y0 - T.py_lo, o1 = cols ? x1 - T.px_lo : y1 - T.py_lo;
     const uint64_t seg = cols ? bit_range(y0 - T.py_lo, y1 - T.py_lo) : bit_range(x0 - T.px_lo, x1 - T.px_lo);
-    for (int32_t o = o0; o <= o1; o += 4) {
-        const uint64_t all4 = load_mask(fin, o) & load_mask(fin, min(o + 1, o1)) & load_mask(fin, min(o + 2, o1)) & load_mask(fin, min(o + 3, o1));
-        if (~all4 & seg) return true;
+    if constexpr (FOUR && VF_FIN4) {
+        const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
+        for (int32_t g = o0 >> 2; g <= (o1 >> 2); ++g)
+            if (~load_mask(fin4, g) & seg) return true;
+        return false;
+    } else {
+        for (int32_t o = o0; o <= o1; o += 4) {
+            const uint64_t all4 = load_mask(fin, o) & load_mask(fin, min(o + 1, o1)) & load_mask(fin, min(o + 2, o1)) & load_mask(fin, min(o + 3, o1));
+            if (~all4 & seg) return true;
+        }
+        return false;
     }
-    return false;
+}
+
+// FOUR-LINE MASKS (round 5).  Every occlusion test in this kernel asks the same thing of the final-pixel masks: "is there an open
+// pixel in this range on ANY of these adjacent lines" -- the block and triangle tests four lines per step, the line groups of the
+// raster four lines per group -- and each step was four 64-bit LDS loads, three min() for the range's end, three ANDs.  The AND of
+// the masks of lines 4 g .. 4 g + 3 is kept beside them instead, rebuilt by the wave that has just rescanned (32 lanes, four loads
+// each): one load per step.  The steps are aligned to multiples of four lines of the tile, not to the box: a step at the box's end
+// also sees up to three lines outside it -- their open pixels can only make the answer "open", the conservative side.
+__device__ __forceinline__ void refresh_fin4(const uint32_t *colfin, const uint32_t *rowfin, uint32_t *colfin4, uint32_t *rowfin4, uint32_t lane)
+{
+    if (lane < 32u) {
+        const uint32_t g = lane & 15u;
+        const uint32_t *src = lane < 16u ? colfin : rowfin;
+        uint32_t *dst = lane < 16u ? colfin4 : rowfin4;
+        const uint32_t lo = src[8u * g] & src[8u * g + 2u] & src[8u * g + 4u] & src[8u * g + 6u];
+        const uint32_t hi = src[8u * g + 1u] & src[8u * g + 3u] & src[8u * g + 5u] & src[8u * g + 7u];
+        dst[2u * g] = lo; dst[2u * g + 1u] = hi;
+    }
 }
 
 // One wave rescans the whole tile: which pixels are owned by a primitive with (id + 1) >= first_id?  Those can never
@@ -1490,6 +1554,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ uint32_t s_rc[1024];                        // per block row: first | end << 16 of the blocks that can reach this tile column (kept from the row mask pass)
     __shared__ uint32_t s_colfin[kTileW * 2];
     __shared__ uint32_t s_rowfin[kTileH * 2];
+    __shared__ uint32_t s_colfin4[kTileW / 4 * 2], s_rowfin4[kTileH / 4 * 2];   // four-line masks (refresh_fin4)
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
     __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
@@ -1531,7 +1596,7 @@ next_item:
 #endif
     const uint32_t tile = work_tile(item);
     TileCtx T;
-    T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin;
+    T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin; T.colfin4 = s_colfin4; T.rowfin4 = s_rowfin4;
     const TilePlace tp = tile_rect(P, tile, T.px_lo, T.px_hi, T.py_lo, T.py_hi);
     const uint32_t tcol = tp.tx;
     const int32_t tile_x0 = T.px_lo;                       // the tile's left edge (T.px_lo becomes the strip's below)
@@ -1543,6 +1608,7 @@ next_item:
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
     for (int k = tid; k < kTileW * 2; k += kTileThreads) s_colfin[k] = 0u;
     for (int k = tid; k < kTileH * 2; k += kTileThreads) s_rowfin[k] = 0u;
+    if (tid < kTileW / 4 * 2) { s_colfin4[tid] = 0u; s_rowfin4[tid] = 0u; }
     if (tid < 16) s_rows[tid] = 0ull;
     if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
 #ifdef VF_DBG_PULLS
@@ -1648,8 +1714,8 @@ next_item:
                     const PixelBox box0 = V.recs[i0].box, box1 = V.recs[i1].box;
                     const float4 seg0 = cap_seg[i0], seg1 = cap_seg[i1];
                     const float rad0 = cap_rad[i0], rad1 = cap_rad[i1];
-                    if (block_is_candidate(box0, seg0, rad0, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b0 >> 5)], 1u << (b0 & 31u)); ++cnt; }
-                    if (in1 && block_is_candidate(box1, seg1, rad1, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b1 >> 5)], 1u << (b1 & 31u)); ++cnt; }
+                    if (block_is_candidate<GROUPS>(box0, seg0, rad0, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b0 >> 5)], 1u << (b0 & 31u)); ++cnt; }
+                    if (in1 && block_is_candidate<GROUPS>(box1, seg1, rad1, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b1 >> 5)], 1u << (b1 & 31u)); ++cnt; }
                 }
                 // the row's eight lanes: quad, the other quad (DPP, no LDS round trips)
                 cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
@@ -1702,7 +1768,7 @@ next_item:
                 for (int r = 0; r < kRowsAtOnce; ++r) {
                     const uint32_t k = k0 + (uint32_t)r * kWaves;
                     if (k >= nrowsteps) continue;                                   // uniform
-                    const unsigned long long m = __ballot(in[r] && block_is_candidate(box[r], seg[r], rad[r], T));
+                    const unsigned long long m = __ballot(in[r] && block_is_candidate<GROUPS>(box[r], seg[r], rad[r], T));
                     if (lane == 0) s_hit[k][g] = m;
                     cnt[r] += (uint32_t)__popcll(m);
                 }
@@ -1883,7 +1949,7 @@ next_item:
                         const uint32_t cell = code >> 1, odd = code & 1u;
                         const uint32_t va = (cell >> 3) * kBlockVerts + (cell & 7u);
                         const int2 q0 = sXY[wave][odd ? va + 1u : va], q1 = sXY[wave][va + kBlockVerts], q2 = sXY[wave][odd ? va + kBlockVerts + 1u : va + 1u];
-                        keep = classify_alive(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, nlines VF_RC(, RC));
+                        keep = classify_alive<GROUPS>(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, nlines VF_RC(, RC));
                     }
                     const unsigned long long m = __ballot(keep);
 #if VF_BALANCE
@@ -1989,6 +2055,10 @@ next_item:
                 const int32_t sw = T.px_hi - T.px_lo + 1, sh = T.py_hi - T.py_lo + 1;
                 const uint32_t nfinal = sw <= 16 ? rescan_strip(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], sw, sh)
                                                  : rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, sh);
+                if constexpr (GROUPS && VF_FIN4) {
+                    __builtin_amdgcn_wave_barrier();                       // (this wave's mask stores are in the DS queue: the loads below come behind them)
+                    refresh_fin4(s_colfin, s_rowfin, s_colfin4, s_rowfin4, lane);
+                }
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) { s_done = 1u; atomicOr(&s_next, 0x40000000u); } }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
@@ -2019,6 +2089,8 @@ next_item:
             if (lane == 0) s_part[wave] = nfinal;
         }
         __syncthreads();
+        if constexpr (GROUPS && VF_FIN4)
+            if (wave == 0) refresh_fin4(s_colfin, s_rowfin, s_colfin4, s_rowfin4, lane);   // (the other waves may start the next chunk on the old four-line masks: they lag, they do not lie)
         uint32_t all = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) all += s_part[w];
