@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
 #define VF_BALANCE 1
 #endif
 #ifndef VF_WIDE_LINES
-#define VF_WIDE_LINES 20
+#define VF_WIDE_LINES 28
 #endif
 #ifndef VF_BAL_GAIN
 #define VF_BAL_GAIN 2
