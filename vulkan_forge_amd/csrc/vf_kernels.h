@@ -550,10 +550,10 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
 #else
     const int32_t ng = (n_outer >> 2) + 1;                 // group g = lines 4 g .. min(4 g + 3, n_outer); at most 16
 #endif
-    // (a triangle whose lanes have a line or two each gains nothing from the test -- a 4-pixel strip's triangles have four lines in
-    //  all: their groups all count as open, and a wave without any other triangle skips the loop)
+    // (VF_GROUP_MIN k: a triangle with no more than k lines per lane skips the test, its groups all count as open.  Round 4 ran with 1;
+    //  since a group's test is one LDS word -- round 5 -- every triangle is tested: C4 -0.4 %)
 #ifndef VF_GROUP_MIN
-#define VF_GROUP_MIN 1
+#define VF_GROUP_MIN 0
 #endif
     const bool test_groups = n_outer + 1 > VF_GROUP_MIN * nsub;
     gmask = test_groups ? 0u : (1u << ng) - 1u;
@@ -1529,9 +1529,25 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
     constexpr int kRescanEvery = VF_RESCAN_EVERY;          // publish new masks when the frontier moved this many steps
     __shared__ uint32_t s_vis[kTileW * kTileH];
-    __shared__ int2 sXY[kWaves][kNV];                      // per wave: snapped vertices of the current block (from k_block_setup)
-    __shared__ uint8_t sC[kWaves][2 * kBlockCells * kBlockCells];   // per wave: the block's alive primitives (cell << 1 | odd), compacted
-    __shared__ uint8_t sS[kWaves][2 * kBlockCells * kBlockCells];   // per wave: those of them that survive against this tile
+    // The waves' private arrays of the block loop share their LDS with the ballots of the list building (s_hit): the ballots are dead
+    // from the barrier behind the list fill to the barrier behind the block loop, the private arrays live only between the two.  The
+    // kernel's LDS falls from 80.5 to 64 KB: two of its workgroups (this frame's last, the next frame's first) then leave a CU 32 KB for
+    // the set-up pass that runs beside them, where they left 2.8 -- C4 -1.4 %, top-down camera -0.9 % (round 5; spent on chunks of 192
+    // block rows instead, the 16 KB lose: 0.7189 -> 0.7239 ms).
+    constexpr int kBlockPrims = 2 * kBlockCells * kBlockCells;
+    struct WaveLds {
+        int2 xy[kWaves][kNV];                              // per wave: snapped vertices of the current block (from k_block_setup)
+        uint8_t alive[kWaves][kBlockPrims];                // per wave: the block's alive primitives (cell << 1 | odd), compacted
+        uint8_t surv[kWaves][kBlockPrims];                 // per wave: those of them that survive against this tile
+        uint8_t lines[kWaves][kBlockPrims];                // per wave: ... and how many lines each of them has inside the tile
+    };
+    constexpr size_t kHitBytes = sizeof(unsigned long long) * kMaxSteps * kHitWords;
+    __shared__ __attribute__((aligned(16))) unsigned char s_overlay[sizeof(WaveLds) > kHitBytes ? sizeof(WaveLds) : kHitBytes];
+    unsigned long long (&s_hit)[kMaxSteps][kHitWords] = *reinterpret_cast<unsigned long long (*)[kMaxSteps][kHitWords]>(s_overlay);   // 64-bit ballots per block row (nb <= 1024)
+    WaveLds &s_wave = *reinterpret_cast<WaveLds *>(s_overlay);
+    int2 (&sXY)[kWaves][kNV] = s_wave.xy;
+    uint8_t (&sC)[kWaves][kBlockPrims] = s_wave.alive;
+    uint8_t (&sS)[kWaves][kBlockPrims] = s_wave.surv;
 #ifndef VF_BALANCE
 #define VF_BALANCE 1
 #endif
@@ -1542,10 +1558,9 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
 #define VF_BAL_GAIN 2
 #endif
 #if VF_BALANCE
-    __shared__ uint8_t sL[kWaves][2 * kBlockCells * kBlockCells];   // per wave: ... and how many lines each of them has inside the tile
+    uint8_t (&sL)[kWaves][kBlockPrims] = s_wave.lines;
 #endif
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
-    __shared__ unsigned long long s_hit[kMaxSteps][kHitWords];
     __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
     __shared__ uint16_t s_words[kMaxSteps];                // per step: first | end << 8 of the 64-block groups its ballots were taken for
     __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
