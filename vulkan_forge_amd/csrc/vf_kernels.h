@@ -620,11 +620,17 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
         }
         const int32_t ol = o_base + o;
         VF_RC(RC.painted += (uint32_t)__popcll(bits); RC.paint_lines += bits ? 1u : 0u;)
+        // vis_index(ol, k) for a column, vis_index(k, ol) for a row: (cols ? k : ol) * 64 + ((ol + k) & 63) -- as arithmetic: the compiler
+        // made the choice a divergent branch inside this innermost loop (ten scalar instructions per painted pixel)
+        // (byte offsets: line * 256 + ((ol + k) & 63) * 4)
+        static_assert(kTileW == 64, "the paint loop's index arithmetic");
+        const uint32_t ol4 = (uint32_t)ol << 2, line4 = cols ? 0u : ol4 << 6;
         while (bits) {
-            const int32_t k = __builtin_ctzll(bits);
+            const uint32_t k = (uint32_t)__builtin_ctzll(bits);
             bits &= bits - 1;
             VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_paint++;)
-            atomicMax(&T.vis[cols ? vis_index(ol, k) : vis_index(k, ol)], word);
+            const uint32_t off = __umul24(k, cols ? 256u : 0u) + line4 + (((k << 2) + ol4) & 252u);
+            atomicMax(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(T.vis) + off), word);
         }
     }
 }
