@@ -152,7 +152,8 @@ def toolchain():
     start another program in its place) -- a compiler bump shows up in the bench line"""
     try:
         info = json.load(open(os.path.join(ROOT, "vulkan_forge_amd", "build_info.json")))
-        return {"hipcc": info.get("hipcc"), "tuning_flags": info.get("tuning_flags"), "built_lib_sha256": info.get("lib_sha256")}
+        return {"hipcc": info.get("hipcc"), "tuning_flags": info.get("tuning_flags"), "tuning_flags_applied": info.get("tuning_flags_applied", True),
+                "built_lib_sha256": info.get("lib_sha256"), **({"note": info["note"]} if info.get("note") else {})}
     except Exception as e:  # noqa: BLE001
         return {"hipcc": None, "error": repr(e)}
 

@@ -57,3 +57,24 @@ def test_the_tile_kernel_keeps_the_properties_its_build_flags_buy():
         assert not deep, f"{name}: scratch accesses inside the chunk loop or below: {deep}"
     # the set-up pass must fit beside the tile kernel: 512 - 4 waves x 96 registers leave 128 per SIMD
     assert int(records["k_block_setup"]["NumVgprs"]) <= 64, records["k_block_setup"]
+
+
+def test_build_survives_a_compiler_that_refuses_a_tuning_switch(tmp_path, monkeypatch):
+    """the eight -mllvm switches are LLVM internals.  A ROCm that renames one must cost the tuning, not the round:
+    the compile is repeated without them, build_info.json records `tuning_flags_applied: false`, and the library works (here: it
+    loads and exports the C-ABI; no GPU needed).  Everything is redirected to a scratch directory -- the in-tree library stays."""
+    import ctypes
+    import json
+
+    import __graft_entry__ as g
+    lib, info = str(tmp_path / "libvf_hip.so"), str(tmp_path / "build_info.json")
+    monkeypatch.setattr(g, "HIP_LIB", lib)
+    monkeypatch.setattr(g, "BUILD_INFO", info)
+    applied, note = g._compile_hip(tuning=[*g.HIPCC_TUNING, "-mllvm", "-vf-no-such-switch-in-this-llvm"])
+    assert applied is False and note and "vf-no-such-switch" in note
+    g._lint(lib)
+    g._write_build_info(applied, note)
+    rec = json.load(open(info))
+    assert rec["tuning_flags_applied"] is False and "-mllvm" not in rec["flags"] and rec["note"]
+    h = ctypes.CDLL(lib)
+    assert h.vf_terrain_render and h.vf_ctx_create

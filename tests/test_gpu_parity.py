@@ -488,6 +488,34 @@ def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, ora
         t.close()
 
 
+def test_a_plan_thrown_away_while_its_set_up_pass_still_runs(cabi, oracle, luts):
+    """Round 6 (advisor): vf_terrain_render is asynchronous.  A caller that rests on one view (a plan for the next frame is queued
+    behind every frame) and then calls render, set_uniforms, render WITHOUT a sync throws a plan away whose set-up pass -- on its own
+    stream -- may still be writing the records the new plan's block boxes rewrite.  A large grid keeps that pass busy; the second
+    view shows a corner only, so whole 16-block segments the stale pass works on are not needed (and never rewritten) in the new one."""
+    W, H, G = 768, 768, 2048
+    h = heightmap(47, G)
+    corner = ((2.1, 0.9, 2.2), (1.25, -0.1, 1.2), (0.0, 1.0, 0.0), 18.0, 0.1, 100.0)
+    t = cabi.Terrain(W, H, G, luts["magma"])
+    try:
+        t.set_shade_precision(0)
+        t.set_height(h)
+        ua, ub = oracle.look_at_uniforms(1, W, H, *DEFAULT_CAMERA), oracle.look_at_uniforms(1, W, H, *corner)
+        refs = {k: oracle.render_terrain(u, W, H, G, h, luts["magma"], nthreads=8, want_vis=False)[0] for k, u in (("a", ua), ("b", ub))}
+        for rnd in range(3):
+            for first, second, want in ((ua, ub, "b"), (ub, ua, "a")):
+                t.set_uniforms(first)
+                for _ in range(5):
+                    t.render(); t.sync()                        # at rest: the last call queued the next frame's plan
+                t.render()                                      # takes that plan, queues another one behind this frame ...
+                t.set_uniforms(second)
+                t.render()                                      # ... which is not this frame's: dropped while it may still run
+                t.sync()
+                assert np.array_equal(t.read_rgba(), refs[want]), (rnd, want)
+    finally:
+        t.close()
+
+
 def test_orbiting_camera_back_to_back(cabi, oracle, luts):
     """A camera that moves the picture by more than a tile per frame makes the plan wait for the previous frame's feedback
     instead of overlapping it (vf_hip.hip: kFreshFeedbackPx); slow motion keeps the overlap.  Frames are queued back to back

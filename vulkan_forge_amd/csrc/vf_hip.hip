@@ -162,7 +162,29 @@ struct vf_ctx {
     hipStream_t side = nullptr, side2 = nullptr, copy = nullptr;
     uint8_t *d_maps = nullptr;   // [kMaxStripeMaps][kMaxStripes] owner tables of the registered stripe maps, uploaded on first use (vf_stitch_tiles_device)
     uint64_t maps_uploaded = 0;  // bit k: map k is there
+    // The members above that are made on first need are shared by every handle of the context, and the drop-in module keeps ONE context
+    // and releases the GIL while it renders: two objects drawing their second frames on two threads would both find `side` missing.
+    std::mutex lazy_mu;
 };
+
+// the context's plan streams, made once (3-10 ms each), under the context's lock
+static hipError_t ctx_side_streams(vf_ctx *c, hipStream_t *side, hipStream_t *side2)
+{
+    std::lock_guard<std::mutex> lk(c->lazy_mu);
+    hipError_t e = hipSuccess;
+    if (!c->side) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess && !c->side2) e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
+    *side = c->side; *side2 = c->side2;
+    return e;
+}
+static hipError_t ctx_copy_stream(vf_ctx *c, hipStream_t *copy)
+{
+    std::lock_guard<std::mutex> lk(c->lazy_mu);
+    hipError_t e = hipSuccess;
+    if (!c->copy) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+    *copy = c->copy;
+    return e;
+}
 
 // What the second half of a frame (draw_frame) needs of the first (plan_frame)
 struct FramePlan {
@@ -266,6 +288,7 @@ struct vf_terrain {
         float u_drawn[32] = {};
     } pre;
     uint64_t last_drawn_gen = 0;         // inputs_gen of the frame drawn last (two frames of one generation: the camera is at rest)
+    bool replan_fresh = false;           // a plan queued ahead was thrown away: the next plan takes the previous frame's tile times (drop_preplan)
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     uint8_t *d_stripe_owner = nullptr;   // tile shards with a registered stripe map: owner per column stripe (kMaxStripes bytes)
     bool use_map = false;
@@ -456,7 +479,15 @@ static hipError_t drop_preplan(vf_terrain *t)
     t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
     t->camera_moving = R.camera_moving; t->was_moving = R.was_moving; t->have_drawn = R.have_drawn;
     std::memcpy(t->u_drawn, R.u_drawn, sizeof t->u_drawn);
-    return t->side ? hipMemsetAsync(R.K.seg_count, 0, sizeof(uint32_t), t->side) : hipSuccess;
+    // The stale plan's k_plan_sort has already zeroed this set's tile times and replaced its flag words: the frame that is planned in
+    // its place reads the PREVIOUS frame's (complete: the caller was idle when the plan went out) -- plan_frame's `fresh` mode.
+    t->replan_fresh = true;
+    if (!t->side) return hipSuccess;
+    // The stale chain ran on `side`, the stale set-up pass on `side2`: the frame planned next rewrites this set's block boxes, records
+    // and segment list from `side`, and must not do so while the stale set-up pass still reads and writes them.
+    hipError_t e = hipStreamWaitEvent(t->side, t->ps[R.K.set].set_up, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(R.K.seg_count, 0, sizeof(uint32_t), t->side);
+    return e;
 }
 
 // A plan state's buffers and events, made when the state is first used (frame 0: at construction; frame 1: by that frame).
@@ -1017,7 +1048,7 @@ static bool fast_shading(const vf_terrain *t) { return t->precision == VF_PRECIS
 // side streams (a handle's first frame: on `s`); it touches plan state only.  draw_frame: the kernels on the caller's stream.  What the
 // second half needs of the first travels in a FramePlan, so that the first half of the NEXT frame can be queued ahead of its call
 // (vf_terrain::pre, render_impl).
-static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
+static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = false)
 {
     FrameParams &P = K.P;
     build_params(t, P);
@@ -1031,10 +1062,7 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
     // plan chain's events come into play with the second frame.
     const bool solo = !t->side && t->frame_no == 1u;
     if (!solo && !t->side) {
-        vf_ctx *c = t->ctx;                                  // (borrowed from the context: made once per process)
-        if (!c->side) VF_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        if (!c->side2) VF_HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
-        t->side = c->side; t->side2 = c->side2;
+        VF_HIP_TRY(ctx_side_streams(t->ctx, &t->side, &t->side2));   // (borrowed from the context: made once per process)
     }
     VF_HIP_TRY(ensure_plan_state(t, set, solo ? s : t->side));
     vf_terrain::PlanState &S = t->ps[set], &O = t->ps[t->last_set];       // this frame's plan state, the previous frame's
@@ -1064,7 +1092,10 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
 #ifdef VF_EXPERIMENTS
     if (std::getenv("VF_NO_MOTION_MAP")) M.on = 0u;
 #endif
-    const bool fresh = young || ((t->camera_moving || t->was_moving) && !M.on);
+    const bool after_drop = t->replan_fresh && t->frames_since_reset >= vf_terrain::kPlanStates;   // (a handle's first frames have their own rules)
+    t->replan_fresh = false;
+    if (after_drop) M.on = 0u;                              // (the motion map reads this set's times too)
+    const bool fresh = young || after_drop || ((t->camera_moving || t->was_moving) && !M.on);
 #ifdef VF_EXPERIMENTS
     const bool first = t->frames_since_reset == 0 && !std::getenv("VF_NO_STATIC_PLAN");
 #else
@@ -1077,8 +1108,11 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
     hipStream_t side = solo ? s : t->side, side2 = solo ? s : t->side2;
+    // (a plan queued ahead of its call records no timing events: its frame has no place in the ring yet -- the slot belongs to whatever
+    //  frame is drawn next -- and vf_terrain_timings would pair them with that frame's draw events; draw_frame records them instead)
+    const bool timed = t->timing && !ahead;
     K.ev_slot = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
-    K.timed = t->timing;
+    K.timed = timed;
     hipEvent_t *ev = t->ev[K.ev_slot];
     // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
     VF_HIP_TRY(hipStreamWaitEvent(side, S.drawn, 0));
@@ -1090,7 +1124,7 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
         VF_HIP_TRY(hipGetLastError());
         t->bounds_dirty = false;
     }
-    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[0], side));
+    if (timed) VF_HIP_TRY(hipEventRecord(ev[0], side));
     const size_t rc_n = (size_t)t->nb * t->ntx;
     uint32_t *rc_lo = S.rc, *rc_hi = S.rc + rc_n;
     // the split quantum comes from the same tile times the plan will read: summed by an extra workgroup of k_block_boxes, or --
@@ -1117,7 +1151,7 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
     hipLaunchKernelGGL(k_block_setup, dim3(nsegs_all), dim3(kSetupThreads), 0, side2,
                        P, t->d_hblk, S.ranges, S.vtx, S.recs, S.gen, S.seg_list, seg_count);
     VF_HIP_TRY(hipEventRecord(S.set_up, side2));
-    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[1], side));
+    if (timed) VF_HIP_TRY(hipEventRecord(ev[1], side));
     if (ntiles) {
         if (fresh) {
             VF_HIP_TRY(hipStreamWaitEvent(side, O.drawn, 0));         // (the block boxes above did not need to wait)
@@ -1134,7 +1168,7 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K)
                            S.flags_new, S.background, ntiles);
     }
     VF_HIP_TRY(hipGetLastError());                              // a failed plan launch is reported here: the probe block below clears hipEventQuery's "not ready"
-    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[2], side));
+    if (timed) VF_HIP_TRY(hipEventRecord(ev[2], side));
     VF_HIP_TRY(hipEventRecord(S.planned, side));
     K.set = set; K.ntiles = ntiles; K.solo = solo; K.motion_starts = motion_starts; K.rc_lo = rc_lo; K.rc_hi = rc_hi; K.seg_count = seg_count;
     return VF_OK;
@@ -1291,7 +1325,7 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
         R.cur_set = t->cur_set; R.frame_no = t->frame_no; R.frames_since_reset = t->frames_since_reset;
         R.camera_moving = t->camera_moving; R.was_moving = t->was_moving; R.have_drawn = t->have_drawn;
         std::memcpy(R.u_drawn, t->u_drawn, sizeof R.u_drawn);
-        if (plan_frame(t, s, R.K) == VF_OK) { R.valid = true; R.gen = t->inputs_gen; }
+        if (plan_frame(t, s, R.K, true) == VF_OK) { R.valid = true; R.gen = t->inputs_gen; }
         else {                                              // (a failed launch: the next call plans for itself and reports it)
             t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
         }
@@ -1338,8 +1372,7 @@ int vf_terrain_render_batch_host(vf_terrain *t, const float *uniforms, uint32_t 
     VF_HIP_TRY(hipSetDevice(t->ctx->device));
     constexpr uint32_t R = vf_terrain::kBatchRing;
     const size_t frame_bytes = (size_t)t->W * t->H * 4, slot_bytes = (size_t)t->ntx * t->nty * kTileW * kTileH * 4;
-    if (!t->ctx->copy) VF_HIP_TRY(hipStreamCreateWithFlags(&t->ctx->copy, hipStreamNonBlocking));
-    t->copy_stream = t->ctx->copy;
+    VF_HIP_TRY(ctx_copy_stream(t->ctx, &t->copy_stream));
     for (uint32_t r = 0; r < R && r < n; ++r) {
         if (!t->d_batch[r]) VF_HIP_TRY(hipMalloc(&t->d_batch[r], slot_bytes));
         if (!t->batch_drawn[r]) VF_HIP_TRY(hipEventCreateWithFlags(&t->batch_drawn[r], hipEventDisableTiming));
@@ -2044,6 +2077,7 @@ int vf_stitch_tiles_device(vf_ctx *ctx, const void *dev_gathered, void *dev_imag
     const uint8_t *d_owner = nullptr;
     if (const StripeMap *m = layout_map(skew)) {            // a registered stripe map: its owner table on this device (uploaded once per context)
         const uint32_t id = (skew >> 21) & 0x3Fu;
+        std::lock_guard<std::mutex> lk(ctx->lazy_mu);
         if (!ctx->d_maps) VF_HIP_TRY(hipMalloc(&ctx->d_maps, (size_t)kMaxStripeMaps * kMaxStripes));
         if (!((ctx->maps_uploaded >> id) & 1ull)) {
             VF_HIP_TRY(hipMemcpy(ctx->d_maps + (size_t)id * kMaxStripes, m->owner.data(), m->owner.size(), hipMemcpyHostToDevice));
