@@ -261,6 +261,11 @@ def main():
     ev_drawn = [torch.cuda.Event() for _ in range(depth)] if side is not None else None
     ev_left = [torch.cuda.Event() for _ in range(depth)] if side is not None else None
 
+    # N > 1: how long a frame's exchange (all-to-all, band stitch, band gather -- everything on the side stream) takes on this rank,
+    # from a pair of events around it; collected in the timed region only
+    collect_ex = [False]
+    ex_events = []
+
     pose = [rank]
 
     def pose_batch(n):
@@ -286,6 +291,9 @@ def main():
         ev_drawn[slot].record(render_stream)
         with torch.cuda.stream(side):
             side.wait_event(ev_drawn[slot])
+            if collect_ex[0]:
+                x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                x0.record(side)
             if args.rehearse:                                        # the same steps with a hop through host memory (gloo)
                 side.synchronize()
                 ex.output(slot).copy_(out)
@@ -316,6 +324,9 @@ def main():
                     g = ex.finish(slot)
                 if rank == 0:
                     t.stitch_tiles(g.data_ptr(), image.data_ptr(), world, ex.skew, ex.stride, side.cuda_stream)
+            if collect_ex[0]:
+                x1.record(side)
+                ex_events.append((x0, x1))
             ev_left[slot].record(side)
         ex.pending_frame[slot] = True
         if args.serial:
@@ -409,6 +420,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t.enable_timing(True, stats=False)                          # HIP events around the kernels; the kernels themselves run as untimed
+        ex_events.clear()
+        collect_ex[0] = ex is not None
         t0 = time.perf_counter()
         if c5:
             t.render_batch(batch_k, None, stream)
@@ -420,7 +433,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        collect_ex[0] = False
         tm = t.timings()
+        tm["exchange_ms"] = [a.elapsed_time(b) for a, b in ex_events]
         tm["frame_tile_ms"], tm["frame_period_ms"] = t.frame_times()
         tm["raster_groups"] = t.raster_groups()
         t.enable_timing(False)
@@ -629,13 +644,41 @@ def main():
                          f"software-adapter path cannot be built in this image"}
 
     # ---- who ran: one entry per rank, so that an N > 1 line proves its own rank count and devices --------------------------------
-    ranks_info = rccl = None
+    # ... and what it spent: a first run on hardware that scales badly must say whether compute, imbalance or the exchange did it
+    ranks_info = rccl = scaling_diag = None
     if world > 1:
         di = t.device_info()
+        pairs = None
+        if not c5:                                                   # one more frame, untimed, with the per-item statistics on: the (tile, block) pairs this rank draws
+            flush()
+            t.set_uniforms(camera_uniforms(args.camera, W, H))
+            t.enable_timing(True, stats=True)
+            t.render(stream)
+            torch.cuda.synchronize()
+            pairs = int(t.timings()["blocks_rasterised"])
+            t.enable_timing(False)
+        period = np.asarray(tm["frame_period_ms"][1:], np.float64)
+        xs = np.asarray(tm.get("exchange_ms") or [], np.float64)
         mine = {"rank": rank, "hip_device": local_rank, "pci_bus_id": f"{di['pci_bus_id']:02x}:{di['pci_device_id']:02x}", "name": di["name"],
-                "local_tiles": t.local_tiles() if not c5 else None, "pid": os.getpid()}
+                "local_tiles": t.local_tiles() if not c5 else None, "pid": os.getpid(),
+                # HIP events of this rank's handle over the timed frames: its kernels on the render stream, and the period between two frames' ends
+                "tile_kernel_ms": float(tm["tile_ms"]), "frame_period_ms": float(np.median(period)) if period.size else None,
+                # events around the frame's exchange on the side stream (all-to-all + band stitch + band gather, or gather + root stitch)
+                "exchange_ms": float(np.median(xs)) if xs.size else None,
+                "local_pairs": pairs}
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, mine)
+        per = [r["frame_period_ms"] for r in ranks_info if r.get("frame_period_ms")]
+        exs = [r["exchange_ms"] for r in ranks_info if r.get("exchange_ms") is not None]
+        if per:
+            slowest = max(ranks_info, key=lambda r: r.get("frame_period_ms") or 0.0)
+            scaling_diag = {"slowest_rank": slowest["rank"], "slowest_rank_frame_period_ms": max(per), "mean_frame_period_ms": float(np.mean(per)),
+                            "imbalance": max(per) / float(np.mean(per)),
+                            # frame k's exchange runs on the side stream while frame k + 1 is drawn: hidden when it is shorter than the frame
+                            # period of the slowest rank AND the step is no longer than that period (plus a tenth: host jitter)
+                            "exchange_ms_max": max(exs) if exs else None,
+                            "exchange_hidden": bool(exs and max(exs) <= max(per) and ms_per_step <= 1.1 * max(per)),
+                            "step_minus_slowest_period_ms": ms_per_step - max(per)}
         rccl = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
                 "version": ".".join(str(v) for v in torch.cuda.nccl.version()) if not args.rehearse else None,
                 "distinct_devices": len({(r["hip_device"], r["pci_bus_id"]) for r in ranks_info})}
@@ -689,6 +732,8 @@ def main():
         if ranks_info is not None:
             out["ranks"] = ranks_info
             out["rccl"] = rccl
+        if scaling_diag is not None:
+            out.update(scaling_diag)
         if api_latency is not None:
             out["api_latency_ms"] = api_latency
         if args.rehearse:

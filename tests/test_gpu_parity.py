@@ -292,7 +292,7 @@ def test_c4_full_size_properties(c4, oracle, cam):
 
 def test_c4_rank_frames_while_the_plan_settles(c4, oracle, luts):
     """One rank of eight (column stripes) at C4: its few far-field tiles are cut into up to 16 strips -- and, in a library built with
-    -DVF_SLICES=1, into depth slices (parts of the tile's descending block-row list, drawn by different workgroups and merged by
+    tools/experiments/r06_kernel_laboratory.patch + -DVF_SLICES=1, into depth slices (parts of the tile's descending block-row list, drawn by different workgroups and merged by
     atomic max).  Every frame on the way from the cold plan to the settled one (whole tiles, then strips by tile time, then strips
     ordered by their own times) equals the whole frame's tiles -- itself compared with the oracle in the next test."""
     from vulkan_forge_amd import cabi as _cabi
@@ -315,7 +315,7 @@ def test_c4_rank_frames_while_the_plan_settles(c4, oracle, luts):
                 for k, (tx, ty) in enumerate(lay):
                     assert np.array_equal(tiles[k], whole[ty * 64:(ty + 1) * 64, tx * 64:(tx + 1) * 64]), (r, frame, tx, ty)
             t.enable_timing(False)
-        assert cut_items > 0                                          # (sliced_items > 0 only with -DVF_SLICES=1)
+        assert cut_items > 0                                          # (sliced_items > 0 only with the depth slices patched back in)
     finally:
         t.enable_timing(False)
         t.set_shard(0, 1, 64)

@@ -1,5 +1,5 @@
 /*
- * walk_model.c -- ANALYSIS TOOL (VERDICT r05 "next round" item 1, step 0).  Not product, not test oracle.
+ * walk_model.c -- ANALYSIS TOOL (VERDICT r05 "next round" item 1, step 0), driven by tests/walk_model/walk_step0.py.  Not product, not the oracle.
  *
  * A CPU model of an IMAGE-ORDER visibility resolver: per pixel, enumerate the grid cells whose primitives can cover the
  * pixel centre in DESCENDING primitive id (cell rows descending, cells of a row descending, odd primitive before even) and

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """what would an image-order (per pixel, descending primitive id) visibility walk cost?
 
-Analysis tool: builds tools/walk_model/walk_model.c (which includes the CPU oracle's vertex arithmetic), renders the frame with the
+Analysis tool (under tests/: it uses the CPU oracle, which tools/ may not): builds tests/walk_model/walk_model.c (which includes the CPU oracle's vertex arithmetic), renders the frame with the
 oracle, walks chosen 64 x 64 tiles pixel by pixel, checks every winner against the oracle's visibility buffer and prints the walk's step
 counts per pixel.  Runs on the CPU only.
 
-    python tools/walk_step0.py --camera default --tiles 34,26 33,26 28,25 --sample 12
+    python tests/walk_model/walk_step0.py --camera default --tiles 34,26 33,26 28,25 --sample 12
 """
 import argparse
 import ctypes as C
@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402  (analysis only)
 
@@ -25,7 +25,7 @@ NAMES = ["srow", "stest", "brow", "btest", "crow", "ctest", "exact", "tri"]
 
 
 def build():
-    src = os.path.join(ROOT, "tools", "walk_model", "walk_model.c")
+    src = os.path.join(ROOT, "tests", "walk_model", "walk_model.c")
     out = os.path.join(ROOT, "build", "libwalk_model.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
@@ -48,7 +48,7 @@ def uniforms(camera, W, H, pose=None):
     return oracle.look_at_uniforms(oracle.KIND_SCENE, W, H, (3.0, 2.0, 3.0), (0, 0, 0), (0, 1, 0), 45.0, 0.1, 100.0)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--camera", default="default", choices=["default", "fill", "orbit"])
     ap.add_argument("--pose", type=int, default=61)
@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--sample", type=int, default=0, help="also walk every k-th tile in both directions")
     ap.add_argument("--eps", type=float, default=1.0 / 32)
     ap.add_argument("--smooth", action="store_true", help="no noise texture: the analytic surface only")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     W, H = (int(v) for v in args.size.split("x"))
     G = args.grid
     lib = build()

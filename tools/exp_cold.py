@@ -24,7 +24,7 @@ for rep in range(3):
         if rep == 1: print(f"   frame {f}: host launch {(t1 - t0) * 1e3:.3f} ms; device: boxes..setup-launch {tm['ranges_ms']:.3f}, plan {tm['plan_ms']:.3f}, clear+tile {tm['tile_ms']:.3f}, plan start -> frame done {tm['total_ms']:.3f}")
         if rep == 2:
             it = t.item_stats()
-            if os.environ.get("VF_DUMP_WEIGHTS") and f < 2:             # library built with -DVF_DBG_WEIGHT: word 1 is the plan's weight
+            if os.environ.get("VF_DUMP_WEIGHTS") and f < 2:             # library built with -DVF_DIAG_ITEM=2: word 1 is the plan's weight
                 np.save(os.path.join(os.path.dirname(__file__), "..", "gpurun_out", f"items_{cam}_f{f}.npy"), it)
                 w, tm = it[:, 1].astype(float), it[:, 3].astype(float)
                 order = np.argsort(-tm)[:12]

@@ -1,4 +1,4 @@
-"""When does each work item of a frame start and end?  (library built with -DVF_DBG_ITEMSTART: the item statistics' block column holds the
+"""When does each work item of a frame start and end?  (library built with -DVF_DIAG_ITEM=3: the item statistics' block column holds the
 start tick.)  Prints the frame's schedule: items in flight over time, when the last item of each weight class starts, the idle share.
 usage: exp_gantt.py [camera] [rank n [stripe_log2]]"""
 import os, sys

@@ -1,4 +1,4 @@
-"""The plan's work list as the tile kernel saw it (library built with -DVF_DBG_WEIGHT: word 1 of the item statistics is the plan's
+"""The plan's work list as the tile kernel saw it (library built with -DVF_DIAG_ITEM=2: word 1 of the item statistics is the plan's
 weight): are the items in descending order of the sort key (k_plan_sort: exponent + five mantissa bits of the weight)?
 usage: VF_HIP_LIB=build/variants/libvf_weight.so python tools/exp_plan_order.py"""
 import os, sys

@@ -1,4 +1,4 @@
-"""Blocks PULLED from the tiles' work lists against blocks drawn (live after the late cull): the library given must be a -DVF_DBG_PULLS build
+"""Blocks PULLED from the tiles' work lists against blocks drawn (live after the late cull): the library given must be a -DVF_DBG_PULLS build (round 6: apply tools/experiments/r06_kernel_laboratory.patch first)
 (its per-item count is pulls), the default library gives the drawn ones.  usage: exp_pulls.py build/variants/libvf_pulls.so"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

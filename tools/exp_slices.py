@@ -1,4 +1,5 @@
-"""What depth slices would cost: variants of the library that draw only a slice of every tile's block rows (VF_DBG_SLICE_LO/HI,
+"""(Round 6: the knobs this drives live in tools/experiments/r06_kernel_laboratory.patch -- apply it first.)
+What depth slices would cost: variants of the library that draw only a slice of every tile's block rows (VF_DBG_SLICE_LO/HI,
 in 1/256 of the tile's row list) with every busy tile cut into the same number of strips (VF_DBG_FORCE_LG).  Sum of the slices'
 pairs and item times against the whole list = the occlusion culling a slice loses by not seeing the slices in front of it."""
 import os, sys

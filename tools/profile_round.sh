@@ -50,7 +50,7 @@ if [ -f build/variants/libvf_gantt.so ]; then for c in pose8 pose0 orbit7 orbit6
 echo "== eight virtual ranks"; timeout -k 10 600 python tools/rehearse_virtual.py 8 > "$out/rehearse_8ranks.json" 2> "$out/rehearse_8ranks.err"; echo "rc=$?"; tail -c 300 "$out/rehearse_8ranks.json"
 echo "== rehearsal"; for n in 2 4; do timeout -k 10 600 python bench.py --gpus $n --rehearse --no-cpu-baseline --steps 5 > "$out/rehearse_${n}ranks.json" 2> "$out/rehearse_${n}ranks.err"; echo "rc=$?"; tail -c 300 "$out/rehearse_${n}ranks.json"; done
 # round 4: where the tile kernel's time goes (build/variants/libvf_phase.so = tools/build_variant.sh phase -DVF_PHASE_PROF), one GPU and a rank of eight;
-# the rank's SQ counters; when each work item starts and ends (libvf_gantt.so = -DVF_DBG_ITEMSTART); which line loop the handle picks per view
+# the rank's SQ counters; when each work item starts and ends (libvf_gantt.so = -DVF_DIAG_ITEM=3); which line loop the handle picks per view
 if [ -f build/variants/libvf_phase.so ]; then echo "== phase cycles"; timeout -k 10 200 python tools/exp_phases.py build/variants/libvf_phase.so > "$out/phase_cycles.log" 2>&1; echo "---- rank 2 of 8" >> "$out/phase_cycles.log"; timeout -k 10 200 python tools/exp_phases.py build/variants/libvf_phase.so 2 8 0 >> "$out/phase_cycles.log" 2>&1; grep -c cycles/pair "$out/phase_cycles.log"; fi
 if [ -f build/variants/libvf_gantt.so ]; then echo "== schedule"; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default > "$out/gantt.log" 2>&1; VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py default 2 8 >> "$out/gantt.log" 2>&1; grep "tile_ms" "$out/gantt.log"; fi
 echo "== rank SQ counters"; tools/pmc_rank.sh $tag/rank_sq 2 8 0 > "$out/rank_sq_counters.txt" 2>&1; tail -4 "$out/rank_sq_counters.txt"

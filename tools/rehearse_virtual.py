@@ -66,7 +66,10 @@ stream = torch.cuda.ExternalStream(ranks[0]["t"].stream_handle(), device=dev)   
 torch.cuda.set_stream(stream)
 
 
-def frame():
+ex_events = []
+
+
+def frame(time_exchange=False):
     for R in ranks:
         R["t"].render(stream.cuda_stream)
     for r, R in enumerate(ranks):                                     # all-to-all: chunk b of rank r -> slot r of rank b
@@ -74,22 +77,52 @@ def frame():
         for bnd in range(N):
             ranks[bnd]["recv"][r].copy_(chunks[bnd], non_blocking=True)
     for bnd, R in enumerate(ranks):                                   # every rank stitches its band, the root gathers them in place
+        if time_exchange:
+            x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            x0.record(stream)
         R["t"].stitch_tiles(R["recv"].data_ptr(), R["band"].data_ptr(), N, layout, chunk_tiles, stream.cuda_stream, height=band_rows)
         image[bnd * band_rows:(bnd + 1) * band_rows].copy_(R["band"], non_blocking=True)
+        if time_exchange:
+            x1.record(stream)
+            ex_events.append((bnd, x0, x1))
 
 
 for _ in range(args.frames):
     frame()
 torch.cuda.synchronize()
-# what one rank costs on its own: steady-state frame period, one rank after another (the other ranks idle)
-periods = []
+# What one rank costs on its own: steady-state frame period, one rank after another (the other ranks idle), measured the way
+# tools/exp_ranks.py does -- 30 settle frames (the plan is feedback driven: round 5 measured after 8, on plans still settling, and
+# reported 2.76x where exp_ranks.py says 3.55x), then the better of two runs of 40 frames; and the handle's own HIP events over a run.
+periods, per_rank = [], []
 for R in ranks:
-    for _ in range(8):
-        R["t"].render(stream.cuda_stream)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t = R["t"]
+    for _ in range(30):
+        t.render(stream.cuda_stream)
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(40):
+            t.render(stream.cuda_stream)
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 40 * 1e3)
+    periods.append(best)
+    t.enable_timing(True, stats=False)
     for _ in range(20):
-        R["t"].render(stream.cuda_stream)
-    torch.cuda.synchronize(); periods.append((time.perf_counter() - t0) / 20 * 1e3)
+        t.render(stream.cuda_stream)
+    torch.cuda.synchronize()
+    tm = t.timings()
+    _tile, period = t.frame_times()
+    t.enable_timing(True, stats=True)
+    t.render(stream.cuda_stream)
+    torch.cuda.synchronize()
+    pairs = int(t.timings()["blocks_rasterised"])
+    t.enable_timing(False)
+    per_rank.append({"tile_kernel_ms": float(tm["tile_ms"]), "frame_period_ms": float(np.median(period[1:])), "local_pairs": pairs})
+for _ in range(3):
+    frame(time_exchange=True)
+torch.cuda.synchronize()
+for r in range(N):                                                  # (here: the band stitch + the band's copy into the image; the all-to-all is device copies)
+    xs = [a.elapsed_time(c) for bnd, a, c in ex_events if bnd == r]
+    per_rank[r]["exchange_ms"] = float(np.median(xs))
 frame()
 torch.cuda.synchronize()
 got = image.clone()
@@ -109,8 +142,10 @@ out = {"rehearsal": f"{N} virtual ranks in one process on one GPU (the pool allo
                                f"64x64 screen tiles in column stripes of {1 << stripe} tile(s) over {N} ranks, all-to-all + one band stitched per rank + bands gathered in place"},
        "gathered_frame_equals_single_rank_frame": equal,
        "ranks": [{"rank": r, "hip_device": 0, "pci_bus_id": f"{di['pci_bus_id']:02x}:{di['pci_device_id']:02x}", "local_tiles": R["t"].local_tiles(),
-                  "frame_period_alone_ms": periods[r]} for r, R in enumerate(ranks)],
+                  "frame_period_alone_ms": periods[r], **per_rank[r]} for r, R in enumerate(ranks)],
        "one_gpu_frame_period_ms": one_gpu, "slowest_rank_ms": max(periods), "emulated_compute_scaling": one_gpu / max(periods),
+       "slowest_rank": int(np.argmax(periods)), "imbalance": max(periods) / float(np.mean(periods)),
+       "exchange_ms_max": max(p["exchange_ms"] for p in per_rank), "exchange_hidden": bool(max(p["exchange_ms"] for p in per_rank) <= max(periods)),
        "stripe_log2": stripe, "band_rows": band_rows, "chunk_tiles": chunk_tiles}
 print(json.dumps(out), flush=True)
 torch.cuda.synchronize()

@@ -22,34 +22,26 @@ namespace vf {
 // ---- constants shared by the kernels -------------------------------------------------------
 constexpr int kBlockCells = 8;                  // grid block = 8 x 8 cells (128 primitives) = the work item of one wave
 constexpr int kBlockVerts = kBlockCells + 1;    // 9 x 9 vertices incl. the shared edges
-#ifndef VF_TILE_W
-#define VF_TILE_W 64
-#endif
-constexpr int kTileW = VF_TILE_W, kTileH = 64;  // screen tile held in LDS (power of two, <= 64 each: masks are 64-bit)
-#ifndef VF_TILE_THREADS
-#define VF_TILE_THREADS 1024
-#endif
+constexpr int kTileW = 64, kTileH = 64;         // screen tile held in LDS (power of two, <= 64 each: masks are 64-bit)
 // strip splitting quantum, in quarters of the even per-item share of last frame's work (kTargetItems items = 4 per CU).  A tile stays
-// whole up to two quanta, i.e. up to VF_SPLIT_QUANTUM_X4 / 8 of a CU's even share of the frame: at 8 the heaviest whole tile alone
+// whole up to two quanta, i.e. up to kSplitQuantumX4 / 8 of a CU's even share of the frame: at 8 the heaviest whole tile alone
 // would take as long as a perfectly balanced frame, beyond it sets the frame time (C4: 6 -> 1.273 ms, 8 -> 1.258, 10 -> 1.45)
-#ifndef VF_SPLIT_QUANTUM_X4
-#define VF_SPLIT_QUANTUM_X4 7
-#endif
-#ifndef VF_WAVE_PRIO
-#define VF_WAVE_PRIO 1            // the tile kernel's waves take SIMD priorities by how close their block is to the finality frontier (vf_kernels.h): 0 off, 1 wide-item instantiation, 2 both
-#endif
-#ifndef VF_RESCAN_EVERY
-#define VF_RESCAN_EVERY 1
-#endif
+constexpr uint32_t kSplitQuantumX4 = 7;
 // Minimum waves per SIMD the tile kernel's register allocation leaves room for.  Its 16 waves per CU are 4 per SIMD; asking for 5
 // caps it at 96 vector registers, which leaves 128 per SIMD free: the set-up kernel of the NEXT frame (side stream, 56 registers)
 // can then run on the same CUs under the tile kernel and fill the issue slots it leaves idle, instead of waiting for its tail.
 #ifndef VF_TILE_MIN_WAVES
 #define VF_TILE_MIN_WAVES 5
 #endif
+// What a work item reports in its statistics word (timing + statistics enabled): 0 the blocks it drew (the product build),
+// 1 / 2 / 3 diagnostics builds for tools/exp_toptiles.py and tools/exp_gantt.py (vf_kernels.h, the end of k_tile's raster phase).
+#ifndef VF_DIAG_ITEM
+#define VF_DIAG_ITEM 0
+#endif
+constexpr int kDiagItem = VF_DIAG_ITEM;
 constexpr int kMaxTileCols = 256;                 // frame width <= 16384 (vf_terrain_create)
 constexpr int kPhaseSlots = 40;                   // u64 diagnostic accumulators behind the per-tile stats (VF_PHASE_PROF builds)
-constexpr int kTileThreads = VF_TILE_THREADS;   // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
+constexpr int kTileThreads = 1024;              // waves per tile workgroup = kTileThreads / 64 (each wave rasterises one block at a time)
 constexpr int kFastExtent = 1 << 24;            // fast path: triangle extent < 65536 px (24.8 fixed point)
 
 constexpr uint32_t F_NEAR = 1u, F_FAR = 2u, F_BAD = 4u, F_NOSNAP = 8u;

@@ -292,7 +292,6 @@ struct vf_terrain {
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     uint8_t *d_stripe_owner = nullptr;   // tile shards with a registered stripe map: owner per column stripe (kMaxStripes bytes)
     bool use_map = false;
-    uint32_t *d_merge = nullptr;         // where the depth slices of a heavy tile meet: [tiles][16] arrival counters, then [tiles][64 x 64] ids; zero between frames
     bool shard_tiles = false;
     uint32_t shade_mode = 0;             // VF_SHADE_REFERENCE / VF_SHADE_SPEC_T32
     uint32_t precision = VF_PRECISION_FAST, precision_frame = VF_PRECISION_FAST;   // fragment arithmetic (of the frame vf_terrain_render drew last)
@@ -567,9 +566,6 @@ int vf_terrain_create(vf_ctx *ctx, uint32_t width, uint32_t height, uint32_t gri
     Carver C;
     C.add((void **)&t->d_height_dummy, sizeof(float), true);      // 1x1 zero texture, src/terrain/mod.rs:342-378
     C.add((void **)&t->d_stats, (4 + 4 * (all_tiles + kSplitBudget) + 2 * kPhaseSlots + (t->nblocks + 31) / 32) * sizeof(uint32_t), true);   // (only [0..4) must be zero) + one bit per block: drawn this frame?
-#if VF_SLICES   // (depth slices are compiled out by default, vf_kernels.h: no merge buffer then)
-    C.add((void **)&t->d_merge, all_tiles * (16 + kTileW * kTileH) * sizeof(uint32_t), true);
-#endif
     C.add((void **)&t->d_xs, n * sizeof(float));
     C.add((void **)&t->d_sinx, n * sizeof(float));
     C.add((void **)&t->d_cosz, n * sizeof(float));
@@ -1215,8 +1211,7 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
     // the variant by default: groups for whole frames and shards of few ranks, none for a rank of many (mostly narrow strips)
     const int guess = t->nranks < (uint32_t)VF_GROUPS_MAX_RANKS ? 1 : 0;
     int pick = guess;
-    if (!VF_GROUPED) pick = 0;
-    else if (forced >= 0) pick = forced != 0;
+    if (forced >= 0) pick = forced != 0;
     else {
         // probes that have completed (frames behind us: never a wait): every probed frame is a sample -- the time its kernels took on
         // the draw stream.  (hipEventQuery's "not ready" is cleared below: the plan launches' errors were collected above.)
@@ -1253,7 +1248,7 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
     const bool groups = pick != 0;
     // timed: the frames of the probe window (from the last settle frame on), and now and then two frames of each variant (one event each)
     const uint32_t e_now = t->g_epoch_frames ? t->g_epoch_frames - 1u : 0u;
-    const bool probe = ntiles && VF_GROUPED && forced < 0 && ((e_now >= 4u && e_now < 20u) || (e_now >= 20u && e_now % 128u >= 124u));
+    const bool probe = ntiles && forced < 0 && ((e_now >= 4u && e_now < 20u) || (e_now >= 20u && e_now % 128u >= 124u));
     vf_terrain::GroupProbe *gp = nullptr;
     if (probe) { gp = &t->gprobe[t->gprobe_head++ % 16]; if (gp->pending) gp = nullptr; }    // (ring full: the frame goes unmeasured)
     if (gp && !gp->b && (hipEventCreate(&gp->a) != hipSuccess || hipEventCreate(&gp->b) != hipSuccess)) gp = nullptr;   // (made on first use: a one-shot handle never probes)
@@ -1269,7 +1264,7 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
                    few(std::min<uint32_t>(64u, ntiles + kSplitBudget)), threads(kTileThreads);
         const SetupView V = { S.vtx, t->d_hblk, S.recs, S.gen };
 #define VF_TILE_ARGS P, V, S.row_ranges, S.cap_seg, S.cap_rad, t->d_lut, t->ctx->d_thresh, S.work_sorted, S.work_count, \
-                     rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo, t->d_merge
+                     rc_lo, rc_hi, t->d_rgba, vis, stats, S.feedback, S.redo
         const bool fast = fast_shading(t);
         // (the complete variant redraws the rare items that met a clipped primitive: always the plain loop)
 #define VF_TILE_LAUNCH(WV, FS)                                                                                         \

@@ -31,9 +31,11 @@
 // Primitive ids are cell-row major, so every primitive of block row r+1 beats every primitive of
 // block row r: after a block row has been rasterised, covered pixels are final.
 //
-// Build-time switches (defaults are the measured optimum at C4; DESIGN.md section 7 has the sweeps): VF_TILE_MIN_WAVES (vf_device.h: the
-// tile kernel's register cap), VF_SPLIT_QUANTUM_X4, VF_RESCAN_EVERY, VF_WAVE_PRIO, VF_CLS_LINES, VF_ROWS_AT_ONCE, VF_MAX_STEPS; VF_SLICES=1 compiles
-// the depth slices in; VF_PHASE_PROF the per-phase cycle counters; VF_DBG_* single-purpose experiment hooks of tools/exp_*.py.
+// Build-time switches: VF_TILE_MIN_WAVES (vf_device.h: the tile kernel's register cap) and two diagnostics builds -- VF_PHASE_PROF
+// (per-phase cycle counters, tools/exp_phases.py) and VF_DIAG_ITEM=1 / 2 / 3 (what an item reports in its statistics word: ticks inside
+// its block loops / the plan's weight / its start time; tools/exp_toptiles.py, exp_gantt.py).  The experiment knobs of rounds 3-5
+// (depth slices, tile priorities, alternative candidate passes, ...) live in tools/experiments/r06_kernel_laboratory.patch: the
+// constants below are their measured optima at C4 (EXPERIMENTS.md has the sweeps).
 #pragma once
 #include "vf_device.h"
 #include "vf_raster.h"
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64) void k_height_blocks(uint32_t n, uint32_t nb, u
 // the projected bottom / top faces, so the whole block lies within `rad` of the segment joining the two face centres
 // (rad = largest centre-to-corner distance + 1 px).  For oblique views the streak a block sweeps is long and thin
 // and the capsule rejects most of the tiles its bounding box crosses.
-// Split quantum of a frame: VF_SPLIT_QUANTUM_X4 quarter-shares of the time the tiles took in the frame whose feedback steers this
+// Split quantum of a frame: kSplitQuantumX4 quarter-shares of the time the tiles took in the frame whose feedback steers this
 // one (sum over its tiles / kTargetItems); 0 = no feedback yet, nothing is split.  One workgroup.
 constexpr uint32_t kTargetItems = 1024;                    // work items that keep 256 CUs busy (4 per CU)
 __device__ __forceinline__ void publish_quantum(const uint32_t *__restrict__ feedback, uint32_t ntiles, uint32_t *__restrict__ quantum)
@@ -112,7 +114,7 @@ __device__ __forceinline__ void publish_quantum(const uint32_t *__restrict__ fee
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((threadIdx.x & 63u) == 0 && sum) atomicAdd(&s_sum, sum);
     __syncthreads();
-    if (threadIdx.x == 0) *quantum = s_sum ? (uint32_t)max(1ull, (unsigned long long)VF_SPLIT_QUANTUM_X4 * s_sum / (4ull * kTargetItems)) : 0u;
+    if (threadIdx.x == 0) *quantum = s_sum ? (uint32_t)max(1ull, (unsigned long long)kSplitQuantumX4 * s_sum / (4ull * kTargetItems)) : 0u;
 }
 __global__ __launch_bounds__(512) void k_quantum(const uint32_t *__restrict__ feedback, uint32_t ntiles, uint32_t *__restrict__ quantum)
 {
@@ -463,9 +465,6 @@ struct TileCtx {
     int32_t py_lo, py_hi;
 };
 
-#ifndef VF_FIN4
-#define VF_FIN4 1           // the occlusion tests read the four-line masks (refresh_fin4); 0: four line masks per step, as before round 5
-#endif
 
 // LDS layout of the visibility tile: rotate each row by its row number so that a walk down a pixel
 // column visits all 32 banks (plain row-major would keep a column in one bank: 64-word row stride).
@@ -501,16 +500,13 @@ __device__ __forceinline__ int32_t floor_to_int(float x)
 }
 // `vb` / `vcode`: where the three vertices came from (this wave's LDS copy of the block, local indices v0 | v1 << 8 | v2 << 16): the
 // exact solver reloads them from there instead of keeping six more registers alive through the line loop for a rare event.
-// GROUPS (VF_GROUPED, round 4): nineteen lines in twenty end in stage 1 -- their span holds no open pixel -- and a wave walks them at
+// GROUPS (round 4): nineteen lines in twenty end in stage 1 -- their span holds no open pixel -- and a wave walks them at
 // the pace of its busiest lane.  So the lanes of a triangle first test its lines four at a time: one bound for the spans of four
 // adjacent lines (span_group: the same three crossings, taken at the end of the group each edge's slope points away from) against
 // the AND of their four final-pixel masks.  A group without an open pixel inside its bound cannot paint and is dropped; the verdicts
 // travel between the triangle's lanes by ballot, and only the lines of the groups that are left are dealt to the lanes and solved as
 // before.  The pixels painted are the same by construction (a dropped line would have failed its own stage-1 test).
 // `first`: the wave's first lane working on this triangle (lanes first .. first + nsub - 1 do, all of them active here).
-#ifndef VF_GROUPED
-#define VF_GROUPED 1
-#endif
 template <bool GROUPS>
 __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, const int2 *vb, uint32_t vcode, int32_t sub, int32_t nsub, uint32_t first VF_RC_ARG)
 {
@@ -537,38 +533,24 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
     // (one loop header or the other: the body below is shared)
     uint32_t gmask = 0, gleft = 0;
     int32_t passed = 0, nlines_left = 0;
-#if VF_FIN4
     const int32_t g_first = o_base >> 2, o_skew = o_base & 3;           // (GROUPS) the tile's four-line group of the box's first line, and that line's place in it
-#endif
     if constexpr (GROUPS) {
     // ---- stage 0: the groups of four lines, one per lane and trip; every lane of the triangle takes the same trips ----
-#if VF_FIN4
     // (groups are the tile's own: lines 4 G .. 4 G + 3 of the tile, G from the one that holds the box's first line -- one load of the
     //  four-line mask per group; the first and the last group may reach beyond the box: bits of `gmask` stay relative to the first)
     const int32_t ng = ((o_base + n_outer) >> 2) - g_first + 1;          // at most 17
     const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
-#else
-    const int32_t ng = (n_outer >> 2) + 1;                 // group g = lines 4 g .. min(4 g + 3, n_outer); at most 16
-#endif
-    // (VF_GROUP_MIN k: a triangle with no more than k lines per lane skips the test, its groups all count as open.  Round 4 ran with 1;
-    //  since a group's test is one LDS word -- round 5 -- every triangle is tested: C4 -0.4 %)
-#ifndef VF_GROUP_MIN
-#define VF_GROUP_MIN 0
-#endif
-    const bool test_groups = n_outer + 1 > VF_GROUP_MIN * nsub;
+    // (round 4 let a triangle with no more than one line per lane skip the test, its groups all counting as open; since a group's test is
+    //  one LDS word -- round 5 -- every triangle is tested: C4 -0.4 %)
+    const bool test_groups = n_outer + 1 > 0;
     gmask = test_groups ? 0u : (1u << ng) - 1u;
     const uint32_t lanes_mask = nsub >= 32 ? 0xFFFFFFFFu : (1u << nsub) - 1u;
     for (int32_t kb = 0; test_groups && kb < ng; kb += nsub) {
         const int32_t g = kb + sub;
         bool open = false;
         if (g < ng) {
-#if VF_FIN4
             const int32_t oa = max(4 * g - o_skew, 0), ob = min(4 * g + 3 - o_skew, n_outer);     // the group's lines inside the box
             const uint64_t done4 = load_mask(fin4, g_first + g);
-#else
-            const int32_t oa = 4 * g, ob = min(oa + 3, n_outer);
-            const uint64_t done4 = load_mask(fin, o_base + oa) & load_mask(fin, o_base + min(oa + 1, ob)) & load_mask(fin, o_base + min(oa + 2, ob)) & load_mask(fin, o_base + ob);
-#endif
             int32_t glo, ghi;
             span_group(S, oa, ob, n_inner, glo, ghi);
             if (!S.regular) { glo = 0; ghi = n_inner; }
@@ -588,13 +570,8 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
         int32_t o = idx;
         if constexpr (GROUPS) {
             while (passed < (idx >> 2)) { gleft &= gleft - 1u; ++passed; }
-#if VF_FIN4
             o = 4 * (int32_t)__builtin_ctz(gleft) + (idx & 3) - o_skew;
             if (o < 0 || o > n_outer) continue;
-#else
-            o = 4 * (int32_t)__builtin_ctz(gleft) + (idx & 3);
-            if (o > n_outer) continue;
-#endif
         }
         const uint64_t done = load_mask(fin, o_base + o);
         if constexpr (!GROUPS) { VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;) }
@@ -695,10 +672,8 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
     const uint64_t seg = cols ? bit_range(py0 - T.py_lo, py1 - T.py_lo) : bit_range(px0 - T.px_lo, px1 - T.px_lo);
     VF_RC(RC.c_reach++;)
     // four lines per step: the loop is a chain of LDS latencies (load, test, branch), not of arithmetic
-#ifndef VF_CLS_LINES
-#define VF_CLS_LINES 4
-#endif
-    if constexpr (FOUR && VF_FIN4) {
+    constexpr int kClsLines = 4;
+    if constexpr (FOUR) {
     // (not in the instantiation for narrow strips: a sliver one or two pixels wide in a 4-pixel strip would answer for the strip's other
     //  columns as well -- a rank of eight at the default camera +1 %)
     const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
@@ -708,11 +683,11 @@ __device__ __forceinline__ bool classify_alive(const TileCtx &T, int32_t X0, int
     }
     return false;
     } else {
-    for (int32_t o = o0; o <= o1; o += VF_CLS_LINES) {
+    for (int32_t o = o0; o <= o1; o += kClsLines) {
         VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_cls++;)
         uint64_t all = load_mask(fin, o);
 #pragma unroll
-        for (int d = 1; d < VF_CLS_LINES; ++d) all &= load_mask(fin, min(o + d, o1));
+        for (int d = 1; d < kClsLines; ++d) all &= load_mask(fin, min(o + d, o1));
         if (~all & seg) return true;
     }
     return false;
@@ -963,7 +938,7 @@ __device__ __forceinline__ bool block_is_candidate(const PixelBox &b, const floa
     const uint32_t *fin = cols ? T.colfin : T.rowfin;
     const int32_t o0 = cols ? x0 - T.px_lo : y0 - T.py_lo, o1 = cols ? x1 - T.px_lo : y1 - T.py_lo;
     const uint64_t seg = cols ? bit_range(y0 - T.py_lo, y1 - T.py_lo) : bit_range(x0 - T.px_lo, x1 - T.px_lo);
-    if constexpr (FOUR && VF_FIN4) {
+    if constexpr (FOUR) {
         const uint32_t *fin4 = cols ? T.colfin4 : T.rowfin4;
         for (int32_t g = o0 >> 2; g <= (o1 >> 2); ++g)
             if (~load_mask(fin4, g) & seg) return true;
@@ -1120,13 +1095,10 @@ __device__ __forceinline__ TilePlace tile_rect(const FrameParams &P, uint32_t ti
 // atomic max) and the slice that arrives last runs the fragment stage.  A slice culls against its own final pixels only: what
 // the slices in front of it cover it does not see, so slices repeat occluded work the way strips repeat block work -- the two
 // cuts together reach 64 pieces at about the repeated work of 16 strips (tools/exp_slices.py).
-// Depth slices are compiled out by default (VF_SLICES 0): on a rank of eight at C4 they shorten the longest item (0.21 -> 0.16 ms)
-// and still lengthen the frame (0.225 -> 0.249 ms) -- the ~25 us every item costs before its first block (row list, candidate tests,
-// list fill, fragment stage) times the extra items outweighs the shorter critical path.  tools/build_variant.sh x -DVF_SLICES=1
-// builds them in; tests/test_gpu_parity.py::test_c4_rank_frames_while_the_plan_settles checks them when they occur.
-#ifndef VF_SLICES
-#define VF_SLICES 0
-#endif
+// Depth slices are not in this file any more (round 6: tools/experiments/r06_kernel_laboratory.patch holds them): on a rank of eight at
+// C4 they shorten the longest item (0.21 -> 0.16 ms) and still lengthen the frame (0.225 -> 0.249 ms) -- the ~25 us every item costs
+// before its first block (row list, candidate tests, list fill, fragment stage) times the extra items outweighs the shorter critical
+// path.  The item word keeps their two fields (always zero).
 constexpr uint32_t kSplitBudget = 2048;                    // extra work items a frame may create by splitting
 __device__ __forceinline__ uint32_t work_tile(uint32_t code) { return code & 0xFFFFFu; }
 __device__ __forceinline__ uint32_t work_part(uint32_t code) { return (code >> 20) & 15u; }
@@ -1180,16 +1152,13 @@ __device__ __forceinline__ uint32_t static_ticks(uint32_t blocks) { return max(b
 // noise terrain fills a tenth of a block's box), hence a depth, not a single layer; and the TOP strip because painter's order
 // draws the near rows first and they sit lowest on the screen: a tile on the silhouette keeps sky in its top strip and is
 // counted to its last row -- those are the frame's heaviest tiles -- while an interior tile stops after the rows that bury it.
-#ifndef VF_EST_DEPTH
-#define VF_EST_DEPTH 24
-#endif
 __device__ __forceinline__ bool capsule_hits_rect(const float4 &seg, float rad, int32_t px_lo, int32_t px_hi, int32_t py_lo, int32_t py_hi);
 __global__ __launch_bounds__(256) void k_plan_estimate(FrameParams P, const PixelBox *__restrict__ row_boxes, const BlockRec *__restrict__ recs,
                                                        const float4 *__restrict__ cap_seg, const float *__restrict__ cap_rad,
                                                        const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ feedback)
 {
-    constexpr uint32_t kEstDepth = VF_EST_DEPTH;
+    constexpr uint32_t kEstDepth = 24;
     __shared__ uint32_t s_est, s_top[8], s_stop;
     int32_t px_lo, px_hi, py_lo, py_hi;
     const TilePlace tp = tile_rect(P, blockIdx.x, px_lo, px_hi, py_lo, py_hi);
@@ -1261,9 +1230,6 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             // 0.52 ms whatever came before).  Shards keep the face value: their cold-start fixed point is the better one for a
             // GPU with few tiles (emulated 2 / 4 ranks: 0.74 / 0.52 ms against 0.84 / 0.55), and their camera rarely moves.
             const bool as_one = P.nranks == 1u && !P.shard_tiles;
-#ifndef VF_PEAK_CUT
-#define VF_PEAK_CUT 1
-#endif
             auto tile_time = [&](uint32_t idx) -> uint32_t {
                 uint32_t t = last_blocks[idx];
                 const uint32_t f = last_flags[idx];            // bits 8..11 log2(strips), 12..13 log2(slices) of the frame the time comes from
@@ -1273,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                 // even share several times -- at 1920 x 1080 (few tiles, a half-empty GPU) the frame waited for such strips with 47-65 % of
                 // the workgroups idle (tools/exp_gantt.py, VF_C5=1).  The strips' own times are in the 64 words behind the tile's.
                 const uint32_t lgp = lg + ((f >> 12) & 3u);     // log2 of the pieces the tile was cut into (strips x depth slices): <= 6, 64 words
-                if (VF_PEAK_CUT && t && lgp && lgp <= 6u) {
+                if (t && lgp && lgp <= 6u) {
                     const uint32_t *pc = last_blocks + (size_t)P.ntx * P.nty + 1u + (size_t)idx * 64u;
                     uint32_t pk = 0;
                     for (uint32_t p = 0; p < (1u << lgp); ++p) pk = max(pk, pc[p]);
@@ -1308,9 +1274,6 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                             }
                     }
                 }
-#ifndef VF_MM_SAMEPOS
-#define VF_MM_SAMEPOS 1
-#endif
                 // The plane is the ground: the silhouette's tiles show terrain ABOVE it -- at the horizon their centres lie beyond the plane's
                 // vanishing line and land nowhere, or on the light tiles under the ridge -- and those are the frame's heaviest tiles: left
                 // whole at the end of the queue one of them ran 0.5 ms after everything else had finished (C5 orbit, pose 16: 0.63 ms
@@ -1318,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
                 // under an orbiting camera, hardly up or down: two tiles to either side, one up and down) ...
                 // (C5 orbit: 0.302 -> 0.292 ms per pose; a floor from this frame's own block ranges -- the static estimate of a first frame --
                 //  under the cut or under the queue order: 0.300 .. 0.306, not kept)
-                if (VF_MM_SAMEPOS) {
+                {
                     const int32_t tx = (int32_t)tp.tx, ty = (int32_t)(blockIdx.x / P.ntx);
                     for (int32_t dy = -1; dy <= 1; ++dy)
                         for (int32_t dx = -2; dx <= 2; ++dx) {
@@ -1350,32 +1313,13 @@ __global__ __launch_bounds__(256) void k_plan(FrameParams P, const PixelBox *__r
             uint32_t lg = 0, lgs = 0;
             if (mean && px_hi - px_lo + 1 == kTileW) {
                 const uint32_t q = seen / mean;
-#if VF_SLICES
-#ifndef VF_SLICE_POLICY
-#define VF_SLICE_POLICY 0
-#endif
-#if VF_SLICE_POLICY == 1      // depth slices first (2, then 4), column strips beyond
-                lgs = q >= 4u ? 2u : q >= 2u ? 1u : 0u;
-                lg = q >= 32u ? 3u : q >= 16u ? 2u : q >= 8u ? 1u : 0u;
-#elif VF_SLICE_POLICY == 2    // two depth slices first, then strips, then four slices
-                lgs = q >= 32u ? 2u : q >= 2u ? 1u : 0u;
-                lg = q >= 16u ? 3u : q >= 8u ? 2u : q >= 4u ? 1u : 0u;
-#else
-                lg = q >= 64u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
-                lgs = q >= 32u ? 2u : q >= 16u ? 1u : 0u;
-#endif
-#else
                 lg = q >= 16u ? 4u : q >= 8u ? 3u : q >= 4u ? 2u : q >= 2u ? 1u : 0u;
-#endif
                 // the launch holds ntiles + kSplitBudget workgroups: reserve the extra items, fall back to fewer pieces
                 while (lg + lgs && atomicAdd(split_budget, (1u << (lg + lgs)) - 1u) + (1u << (lg + lgs)) - 1u > kSplitBudget) {
                     atomicSub(split_budget, (1u << (lg + lgs)) - 1u);
                     if (lgs) --lgs; else --lg;
                 }
             }
-#ifdef VF_DBG_FORCE_LG   // experiments only (tools/exp_slices.py): every busy tile cut the same way (0 only: no budget check)
-            lg = VF_DBG_FORCE_LG; lgs = 0;
-#endif
             // The pieces' weights order the launch (heaviest first).  Cut the way it was in the frame its time comes from, a tile
             // hands every piece the time that piece took then (pieces differ: the slice in front draws more than the one behind,
             // the strip over the ridge more than its neighbour); cut differently, the tile's time is shared evenly.
@@ -1521,19 +1465,15 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
                                                        const uint2 *__restrict__ work, uint32_t *__restrict__ work_count,
                                                        const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi,
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
-                                                       uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo,
-                                                       uint32_t *__restrict__ merge)
+                                                       uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo)
 {
     uint32_t *const redo_count = work_count + 3;           // items handed to the complete variant
     constexpr int kWaves = kTileThreads / 64;
     constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
     constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
-#ifndef VF_MAX_STEPS
-#define VF_MAX_STEPS 128
-#endif
-    constexpr int kMaxSteps = VF_MAX_STEPS;                // block rows per chunk
+    constexpr int kMaxSteps = 128;                // block rows per chunk
     constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
-    constexpr int kRescanEvery = VF_RESCAN_EVERY;          // publish new masks when the frontier moved this many steps
+    constexpr int kRescanEvery = 1;          // publish new masks when the frontier moved this many steps
     __shared__ uint32_t s_vis[kTileW * kTileH];
     // The waves' private arrays of the block loop share their LDS with the ballots of the list building (s_hit): the ballots are dead
     // from the barrier behind the list fill to the barrier behind the block loop, the private arrays live only between the two.  The
@@ -1554,18 +1494,8 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     int2 (&sXY)[kWaves][kNV] = s_wave.xy;
     uint8_t (&sC)[kWaves][kBlockPrims] = s_wave.alive;
     uint8_t (&sS)[kWaves][kBlockPrims] = s_wave.surv;
-#ifndef VF_BALANCE
-#define VF_BALANCE 1
-#endif
-#ifndef VF_WIDE_LINES
-#define VF_WIDE_LINES 28
-#endif
-#ifndef VF_BAL_GAIN
-#define VF_BAL_GAIN 2
-#endif
-#if VF_BALANCE
+    constexpr uint32_t kWideLines = 28, kBalGain = 2;      // lane dealing by line counts: looked at when a survivor has more lines than this / taken when it saves this many trips
     uint8_t (&sL)[kWaves][kBlockPrims] = s_wave.lines;
-#endif
     __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
     __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
     __shared__ uint16_t s_words[kMaxSteps];                // per step: first | end << 8 of the 64-block groups its ballots were taken for
@@ -1579,9 +1509,6 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     __shared__ uint32_t s_part[kWaves];
     __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
     __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
-#ifdef VF_DBG_PULLS
-    __shared__ uint32_t s_dbg;
-#endif
     __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
     __shared__ float s_thr[256];
     __shared__ uint32_t s_per[65];                         // [survivors]: lanes per survivor | ceil(2^16 / that) << 7 | survivors per round << 24
@@ -1609,12 +1536,6 @@ next_item:
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
     // tile: work-list entry -> (tile column, local tile row) -> pixel rectangle of this shard
     const uint32_t item = work[item_idx].x;
-#ifdef VF_TILE_PRIO      // experiment: the frame's heaviest items (the first VF_TILE_PRIO_ITEMS of the sorted list) win the issue arbitration
-#ifndef VF_TILE_PRIO_ITEMS
-#define VF_TILE_PRIO_ITEMS 0xFFFFFFFFu
-#endif
-    if (!COMPLETE) { if (item_idx < (uint32_t)VF_TILE_PRIO_ITEMS) __builtin_amdgcn_s_setprio(VF_TILE_PRIO); else __builtin_amdgcn_s_setprio(0); }
-#endif
     const uint32_t tile = work_tile(item);
     TileCtx T;
     T.vis = s_vis; T.colfin = s_colfin; T.rowfin = s_rowfin; T.colfin4 = s_colfin4; T.rowfin4 = s_rowfin4;
@@ -1632,9 +1553,6 @@ next_item:
     if (tid < kTileW / 4 * 2) { s_colfin4[tid] = 0u; s_rowfin4[tid] = 0u; }
     if (tid < 16) s_rows[tid] = 0ull;
     if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
-#ifdef VF_DBG_PULLS
-    if (tid == 0) s_dbg = 0;
-#endif
     __syncthreads();
     VF_PH(13)                                              // item record, tile state
     // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
@@ -1671,46 +1589,24 @@ next_item:
     __syncthreads();
 
     VF_PH(8)                                                // item start, tile state, row list
-#ifdef VF_DBG_LOOPTIME
-    uint32_t dbg_loop = 0;
-#endif
+    uint32_t dbg_loop = 0;                                 // (VF_DIAG_ITEM=1 only; dead code otherwise)
     const uint32_t hit_words = (P.nb + 63u) / 64u;
     // (the frontier words are read while other waves write them: relaxed atomic loads on the LDS variables themselves -- a `volatile`
     //  pointer loses the address space, the loads become FLAT ones and their 64-bit generic addresses live in (spilled) vector registers)
     auto lds_peek = [](const uint32_t *p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     // a depth slice draws its part of the row list (the complete variant redraws the whole strip, whichever slice filed it)
-#if VF_SLICES
-    const uint32_t lg_slices = COMPLETE ? 0u : work_lg_slices(item);
-#else
     constexpr uint32_t lg_slices = 0u;
-#endif
     uint32_t row_first = 0;
-#if VF_SLICES
-    if (lg_slices) {
-        row_first = (nrows_total * work_slice(item)) >> lg_slices;
-        nrows_total = (nrows_total * (work_slice(item) + 1u)) >> lg_slices;
-    }
-#endif
-#ifdef VF_DBG_SLICE_LO    // experiments only (tools/exp_slices.py): draw a depth slice of every tile's block rows (the picture is wrong)
-    row_first = nrows_total * VF_DBG_SLICE_LO / 256u;
-    nrows_total = nrows_total * VF_DBG_SLICE_HI / 256u;
-#endif
     for (uint32_t cursor = row_first; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
         // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
         //      the ballots are kept for the fill pass ----
         const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
         if (tid == 0) { s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
-#ifndef VF_CAND_PAIRS
-#define VF_CAND_PAIRS 1
-#endif
-#ifndef VF_CAND_PAIRS_MIN_ROWS
-#define VF_CAND_PAIRS_MIN_ROWS 0
-#endif
         // (in the kernel instantiation WITHOUT line groups only -- the one a handle ends up with when its items are narrow strips of
         //  far-field tiles, hundreds of rows each: C4, a rank of eight 0.214 -> 0.199 ms; the other instantiation's wide items have a
         //  dozen rows and lose 1 % to the longer code: measured both ways, EXPERIMENTS.md)
-        if (VF_CAND_PAIRS && !GROUPS && nrowsteps > (uint32_t)VF_CAND_PAIRS_MIN_ROWS) {
+        if (!GROUPS) {
         // Lanes = (row, block) pairs: a row's range holds a dozen blocks in the far field and fewer elsewhere, so a wave takes EIGHT of
         // the chunk's rows at once, eight lanes each (round 4; before: four rows per pass, 64 lanes per row, ten of them busy -- two
         // passes, i.e. two memory round trips, and four times the instructions per chunk).  Two blocks per lane and trip are requested
@@ -1749,10 +1645,7 @@ next_item:
         } else {
         // Four rows per pass: their bounds (pixel box, capsule) are fetched together, so the global-memory latency -- the
         // whole cost of this phase -- is paid once per pass instead of once per row and array.
-#ifndef VF_ROWS_AT_ONCE
-#define VF_ROWS_AT_ONCE 4
-#endif
-        constexpr int kRowsAtOnce = VF_ROWS_AT_ONCE;
+        constexpr int kRowsAtOnce = 4;
         for (uint32_t k0 = wave; k0 < nrowsteps; k0 += kRowsAtOnce * kWaves) {
             uint32_t by[kRowsAtOnce], bx_lo[kRowsAtOnce], bx_hi[kRowsAtOnce], cnt[kRowsAtOnce];
 #pragma unroll
@@ -1852,9 +1745,7 @@ next_item:
 
         // ---- asynchronous raster: waves pull blocks until the list is empty or the tile is final ----
         uint32_t my_blocks = 0;
-#ifdef VF_DBG_LOOPTIME
-        const uint64_t dbg_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+        const uint64_t dbg_t0 = kDiagItem == 1 ? __builtin_amdgcn_s_memrealtime() : 0ull;
         for (;;) {
             // (a finished tile pushes the list counter past the list's end: one LDS round trip tells "nothing left" and "tile final" apart
             //  from "here is your block" -- a separate look at a done flag was one more dependent round trip per block: -1.6 %)
@@ -1862,24 +1753,19 @@ next_item:
             if (lane == 0) idx = atomicAdd(&s_next, 1u);
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
             if (idx >= nlist) break;
-#ifdef VF_DBG_PULLS
-            if (lane == 0) atomicAdd(&s_dbg, 1u);            // (experiment: blocks pulled, live or not)
-#endif
             const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[idx]);
             const uint32_t bx = entry & 0x3FFu, by = (entry >> 10) & 0x3FFu, stepidx = entry >> 20;
-#if VF_WAVE_PRIO
             // WAVE PRIORITY (round 4).  What every wave of the tile culls against -- blocks, triangles, lines, pixels -- is the set of FINAL
             // pixels, and that set grows when the oldest unfinished step completes and its completer has rescanned the tile.  So the
             // wave that holds a block of that step goes first on its SIMD (s_setprio 2), the step behind it next (1), everything
             // younger last (0), and the rescan itself above all of them (3, below): the masks come out earlier and everybody else does
             // less.  Scheduling only -- the same pixels.  C4: one GPU -2 %, top-down camera -5.7 %, a rank of eight at that camera -4 %.
             // In the instantiation for wide items only (GROUPS): the narrow strips of a many-rank shard and the C5 orbit, which the
-            // other instantiation draws, gain nothing (a rank of eight at the default camera +1 %, C5 +-0); VF_WAVE_PRIO=2 has both.
-            if (VF_WAVE_PRIO == 2 || GROUPS) {
+            // other instantiation draws, gain nothing (a rank of eight at the default camera +1 %, C5 +-0).
+            if (GROUPS) {
                 const uint32_t fr_now = lds_peek(&s_frontier);
                 if (stepidx <= fr_now) __builtin_amdgcn_s_setprio(2); else if (stepidx == fr_now + 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             }
-#endif
             // One round trip for everything the block needs from HBM: its record (pixel box, alive masks) and its 81 snapped
             // vertices are requested together, before the box decides whether the block is still worth drawing -- a dependent
             // second trip costs a wave more than the vertices of the blocks that turn out culled.
@@ -1973,15 +1859,11 @@ next_item:
                         keep = classify_alive<GROUPS>(T, q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, nlines VF_RC(, RC));
                     }
                     const unsigned long long m = __ballot(keep);
-#if VF_BALANCE
-                    any_wide = any_wide || __ballot(keep && nlines > (uint32_t)VF_WIDE_LINES) != 0ull;
-#endif
+                    any_wide = any_wide || __ballot(keep && nlines > kWideLines) != 0ull;
                     if (keep) {
                         const uint32_t at = nsurv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         sS[wave][at] = (uint8_t)code;
-#if VF_BALANCE
                         sL[wave][at] = (uint8_t)nlines;
-#endif
                     }
                     nsurv += (uint32_t)__popcll(m);
                 }
@@ -1995,7 +1877,6 @@ next_item:
                     const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_per[min(nsurv, 64u)]);
                     const uint32_t per = pe & 0x7Fu, group = pe >> 24;          // group = survivors per round = 64 / per
                     const uint32_t q = (lane * ((pe >> 7) & 0x1FFFFu)) >> 16, sub = lane - q * per;
-#if VF_BALANCE
                     // Even shares leave the wave waiting for its widest triangle (6.9 trips through the line loop per pair at C4's default
                     // camera where the lines would fill 3.5; 27 against 13 with the fill camera).  When that costs two trips or more, the
                     // lanes are dealt in proportion to the line counts instead: chunks of C = ceil(lines / (64 - survivors)) lines,
@@ -2016,7 +1897,7 @@ next_item:
                             if ((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(m2), 63) <= 64u) C = C2;
                         }
                         const uint32_t trips_now = (uint32_t)(((float)(widest + per - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)per));
-                        if (__builtin_amdgcn_readfirstlane((int)(trips_now >= C + (uint32_t)VF_BAL_GAIN ? 1u : 0u))) {     // (the same in every lane: keep the branch scalar)
+                        if (__builtin_amdgcn_readfirstlane((int)(trips_now >= C + kBalGain ? 1u : 0u))) {     // (the same in every lane: keep the branch scalar)
                             balanced = true;
                             const uint32_t mk = lane < nsurv ? (uint32_t)(((float)(Lk + C - 1u) + 0.5f) * __builtin_amdgcn_rcpf((float)C)) : 0u;   // lanes for survivor `lane`
                             const uint32_t inc = wave_scan_add(mk), start = inc - mk;
@@ -2031,10 +1912,6 @@ next_item:
                             b_used = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                         }
                     }
-#else
-                    constexpr bool balanced = false;
-                    constexpr uint32_t b_mine = 0, b_used = 0;
-#endif
                     for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {      // (balanced: one round)
                         VF_RC(if (lane == 0) rc_iters++;)
                         const uint32_t sidx = sbase + q;
@@ -2065,9 +1942,7 @@ next_item:
             if (lane == 0) got = atomicCAS(&s_lock, 0u, 1u) == 0u ? 1u : 0u;
             got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             if (!got) { VF_PH(5) continue; }                           // somebody else is publishing; masks may lag, never lie
-#if VF_WAVE_PRIO
-            if (VF_WAVE_PRIO == 2 || GROUPS) __builtin_amdgcn_s_setprio(3);   // the publisher of new final-pixel masks: before everything else (above)
-#endif
+            if (GROUPS) __builtin_amdgcn_s_setprio(3);   // the publisher of new final-pixel masks: before everything else (above)
             uint32_t fr = lds_peek(&s_frontier);
             while (fr < nsteps && lds_peek(&s_pending[fr]) == 0u) ++fr;
             const uint32_t pub = lds_peek(&s_published);
@@ -2076,27 +1951,21 @@ next_item:
                 const int32_t sw = T.px_hi - T.px_lo + 1, sh = T.py_hi - T.py_lo + 1;
                 const uint32_t nfinal = sw <= 16 ? rescan_strip(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], sw, sh)
                                                  : rescan_open_rows(s_vis, s_colfin, s_rowfin, lane, s_firstid[fr - 1], row_full, sh);
-                if constexpr (GROUPS && VF_FIN4) {
+                if constexpr (GROUPS) {
                     __builtin_amdgcn_wave_barrier();                       // (this wave's mask stores are in the DS queue: the loads below come behind them)
                     refresh_fin4(s_colfin, s_rowfin, s_colfin4, s_rowfin4, lane);
                 }
                 if (lane == 0) { s_published = fr; if (nfinal >= tile_pixels) { s_done = 1u; atomicOr(&s_next, 0x40000000u); } }
             }
             if (lane == 0) { s_frontier = fr; __threadfence_block(); atomicExch(&s_lock, 0u); }
-#if VF_WAVE_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             VF_PH(5)
         }
         VF_PH(1)
-#if VF_WAVE_PRIO
         __builtin_amdgcn_s_setprio(0);                                 // (the last block's priority ends with the block loop)
-#endif
         if (lane == 0 && my_blocks) atomicAdd(&s_blocks, my_blocks);
         __syncthreads();
-#ifdef VF_DBG_LOOPTIME
-        dbg_loop += (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
-#endif
+        if (kDiagItem == 1) dbg_loop += (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
         if (s_done) break;                                             // uniform
         // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
         {
@@ -2110,7 +1979,7 @@ next_item:
             if (lane == 0) s_part[wave] = nfinal;
         }
         __syncthreads();
-        if constexpr (GROUPS && VF_FIN4)
+        if constexpr (GROUPS)
             if (wave == 0) refresh_fin4(s_colfin, s_rowfin, s_colfin4, s_rowfin4, lane);   // (the other waves may start the next chunk on the old four-line masks: they lag, they do not lie)
         uint32_t all = 0;
 #pragma unroll
@@ -2122,54 +1991,15 @@ next_item:
     VF_PH(6)
     if (stats && tid == 0) {
         atomicAdd(&stats[0], s_blocks);
-#ifdef VF_DBG_LOOPTIME
-        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = dbg_loop;     // (experiment: ticks inside the block loops instead of the block count)
-#elif defined(VF_DBG_PULLS)
-        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_dbg;        // (experiment: blocks pulled instead of blocks drawn)
-#else
-        stats[4 + 4 * item_idx] = item; stats[5 + 4 * item_idx] = s_blocks;
-#endif
-#ifdef VF_DBG_WEIGHT
-        stats[5 + 4 * item_idx] = work[item_idx].y;         // (experiment: the plan's weight of the item instead of the block count)
-#endif
-#ifdef VF_DBG_ITEMSTART
-        stats[5 + 4 * item_idx] = (uint32_t)t_start;        // (experiment: when the item started, 10 ns ticks of the 100 MHz clock -- tools/exp_gantt.py)
-#endif
+        // (diagnostics builds, VF_DIAG_ITEM: 1 ticks inside the block loops, 2 the plan's weight of the item, 3 when the item started --
+        //  10 ns ticks of the 100 MHz clock, tools/exp_gantt.py -- instead of the blocks drawn)
+        stats[4 + 4 * item_idx] = item;
+        stats[5 + 4 * item_idx] = kDiagItem == 1 ? dbg_loop : kDiagItem == 2 ? work[item_idx].y : kDiagItem == 3 ? (uint32_t)t_start : s_blocks;
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
 
     const int32_t item_w = T.px_hi - T.px_lo + 1;
-#if VF_SLICES
-    bool shade = true;
-    if (lg_slices) {                                        // (uniform)
-        // ---- depth slices meet in the tile's words of the merge buffer: max of the ids; the last one to arrive takes the result
-        //      (and leaves the words zero for the next frame) ----
-        uint32_t *const mcount = merge + (tile * 16u + work_part(item));                       // [all tiles][16 strips]
-        uint32_t *const mtile = merge + (size_t)P.ntx * P.nty * 16u + (size_t)tile * (kTileW * kTileH) + (uint32_t)(T.px_lo - tile_x0);
-        const int32_t w_shift = 31 - __builtin_clz(item_w);                                    // (sliced tiles are whole tiles: item_w = 64 >> lg)
-        const int32_t npx = (T.py_hi - T.py_lo + 1) << w_shift;
-        for (int k = tid; k < npx; k += kTileThreads) {
-            const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
-            const uint32_t id = s_vis[vis_index(lx, ly)];
-            if (id) atomicMax(&mtile[ly * kTileW + lx], id);
-        }
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_item = atomicAdd(mcount, 1u);
-        __syncthreads();
-        shade = s_item == (1u << lg_slices) - 1u;
-        if (shade) {
-            if (tid == 0) *mcount = 0u;
-            for (int k = tid; k < npx; k += kTileThreads) {
-                const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
-                s_vis[vis_index(lx, ly)] = atomicExch(&mtile[ly * kTileW + lx], 0u);
-            }
-        }
-        __syncthreads();
-    }
-#else
     constexpr bool shade = true;
-#endif
     // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
     ShadeTables S = { s_lut, s_thr };
     if (shade) {
@@ -2357,21 +2187,12 @@ __global__ __launch_bounds__(256) void k_resolve4(FrameParams P, SetupView V, co
         R.at(kk, rx, ry);
         const uint32_t q = rx * 8u + lq, py = ry * 32u + ly;
         if (!(q < W4 && py < P.H)) return make_uint4(0u, 0u, 0u, 0u);
-#ifdef VF_RESOLVE_NT
-        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(vis) + ((size_t)py * W4 + q));   // read once: do not keep it in the caches
-        return make_uint4(v.x, v.y, v.z, v.w);
-#else
         return vis[(size_t)py * W4 + q];
-#endif
     };
     uint32_t ncov = 0;
     // visibility words are requested kAhead regions ahead: with the few waves per CU that suit the record gathers (below), one
     // 16-byte load in flight per lane would leave HBM idle (bytes in flight = bandwidth x latency)
-#ifndef VF_RESOLVE_AHEAD
-#define VF_RESOLVE_AHEAD 3
-#endif
-    constexpr int kAhead = VF_RESOLVE_AHEAD;
+    constexpr int kAhead = 3;
     uint4 ring[kAhead];
 #pragma unroll
     for (int a = 0; a < kAhead; ++a) ring[a] = R.k + (uint32_t)a * R.stride < R.total ? fetch(R.k + (uint32_t)a * R.stride) : make_uint4(0u, 0u, 0u, 0u);
@@ -2401,13 +2222,7 @@ __global__ __launch_bounds__(256) void k_resolve4(FrameParams P, SetupView V, co
             __builtin_amdgcn_wave_barrier();               // (the next region's words go to the same place)
         }
         if (q < W4 && py < P.H) {
-#ifdef VF_RESOLVE_NT
-            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-            u4v o; o.x = out.x; o.y = out.y; o.z = out.z; o.w = out.w;
-            __builtin_nontemporal_store(o, reinterpret_cast<u4v *>(rgba) + ((size_t)py * W4 + q));
-#else
             rgba[(size_t)py * W4 + q] = out;
-#endif
         }
         ncov += (id.x ? 1u : 0u) + (id.y ? 1u : 0u) + (id.z ? 1u : 0u) + (id.w ? 1u : 0u);
         R.k = kn;
