@@ -547,10 +547,10 @@ def main():
     api_latency = None
     if rank == 0 and world == 1 and not args.no_extra and not args.no_api_latency and not c5:
         import tempfile
-        api_latency = {"clock": "host wall clock around the call, best of 4 after one warm-up call", "png_threads": os.environ.get("VF_PNG_THREADS", "default (up to 16)")}
+        api_latency = {"clock": "host wall clock around the call, best of 8 after two warm-up calls", "png_threads": os.environ.get("VF_PNG_THREADS", "default (up to 16)")}
         with tempfile.TemporaryDirectory() as tmpd:
-            def best(fn, n=4):
-                fn()
+            def best(fn, n=8):
+                fn(); fn()
                 ts = []
                 for _ in range(n):
                     c0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - c0) * 1e3)

@@ -442,10 +442,13 @@ def test_feedback_scheduling_never_changes_the_frame(cabi, oracle, luts):
         t.close()
 
 
-def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, oracle, luts):
+@pytest.mark.parametrize("plan_streams", [False, True])
+def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, oracle, luts, plan_streams):
     """Round 5: a caller that waits for every frame of a camera at rest gets the NEXT frame's plan queued behind each frame
     (vf_hip.hip::render_impl).  Whatever changes between two frames -- camera, heights, exaggeration, shade mode, shard, timing -- the plan
-    made ahead is for other inputs and must be thrown away: every frame below equals the oracle's."""
+    made ahead is for other inputs and must be thrown away: every frame below equals the oracle's.
+    Round 6: a handle whose caller has always waited has no plan streams -- its plan made ahead goes out behind the next READ-BACK's
+    copy, on the caller's stream (plan_streams False: every settle frame is read back); two frames in flight once make the streams."""
     W, H, G = 640, 400, 192
     h0, h1 = heightmap(41, G), heightmap(42, G)
     cams = [DEFAULT_CAMERA, ((2.5, 1.6, -2.8), (0.1, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.1, 100.0), FILL_CAMERA]
@@ -453,10 +456,15 @@ def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, ora
     try:
         t.set_shade_precision(0)
         t.set_height(h0)
+        if plan_streams:
+            t.set_uniforms(oracle.look_at_uniforms(1, W, H, *cams[0]))
+            t.render(); t.render(); t.sync()                     # a frame arriving while another is in flight: the handle takes the plan streams
 
         def settle_and_check(u, h, what, **kw):
             for _ in range(5):                                   # synchronous frames of one set of inputs: from the fourth on the plan comes from the call before
-                t.render(); t.sync()
+                t.render()
+                if plan_streams: t.sync()
+                else: t.read_rgba()                              # (the read-back is what sends a waiting caller's next plan on its way)
             ref, ref_vis = oracle.render_terrain(u, W, H, G, h, luts["viridis"], nthreads=8, **kw)
             assert np.array_equal(t.read_rgba(), ref), what
             return ref_vis
@@ -488,7 +496,8 @@ def test_plan_queued_ahead_is_used_only_for_the_inputs_it_was_made_for(cabi, ora
         t.close()
 
 
-def test_a_plan_thrown_away_while_its_set_up_pass_still_runs(cabi, oracle, luts):
+@pytest.mark.parametrize("plan_streams", [True, False])
+def test_a_plan_thrown_away_while_its_set_up_pass_still_runs(cabi, oracle, luts, plan_streams):
     """Round 6 (advisor): vf_terrain_render is asynchronous.  A caller that rests on one view (a plan for the next frame is queued
     behind every frame) and then calls render, set_uniforms, render WITHOUT a sync throws a plan away whose set-up pass -- on its own
     stream -- may still be writing the records the new plan's block boxes rewrite.  A large grid keeps that pass busy; the second
@@ -502,12 +511,18 @@ def test_a_plan_thrown_away_while_its_set_up_pass_still_runs(cabi, oracle, luts)
         t.set_height(h)
         ua, ub = oracle.look_at_uniforms(1, W, H, *DEFAULT_CAMERA), oracle.look_at_uniforms(1, W, H, *corner)
         refs = {k: oracle.render_terrain(u, W, H, G, h, luts["magma"], nthreads=8, want_vis=False)[0] for k, u in (("a", ua), ("b", ub))}
+        if plan_streams:
+            t.set_uniforms(ua)
+            t.render(); t.render(); t.sync()                    # two frames in flight: the handle takes the context's plan streams
         for rnd in range(3):
             for first, second, want in ((ua, ub, "b"), (ub, ua, "a")):
                 t.set_uniforms(first)
                 for _ in range(5):
-                    t.render(); t.sync()                        # at rest: the last call queued the next frame's plan
+                    t.render()                                  # at rest: the last call queued the next frame's plan (plan streams) ...
+                    if plan_streams: t.sync()
+                    else: t.read_rgba()                         # ... or its read-back did, behind the copy (none: a waiting caller)
                 t.render()                                      # takes that plan, queues another one behind this frame ...
+                if not plan_streams: t.read_rgba()
                 t.set_uniforms(second)
                 t.render()                                      # ... which is not this frame's: dropped while it may still run
                 t.sync()

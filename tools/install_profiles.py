@@ -58,7 +58,7 @@ for n in (2, 4, 8):
     if os.path.exists(os.path.join(G, f"rehearse_{n}ranks.json")):
         open(os.path.join(P, f"{prefix}_rehearse_{n}ranks.json"), "w").write(last_json_line(os.path.join(G, f"rehearse_{n}ranks.json")) + "\n")
 copy("kernel_stats.csv", "kernel_stats.csv")
-for n in ("fetch_default", "write_default", "frag_fetch_default", "frag_write_default", "frag_fetch_fill", "frag_write_fill", "frag_l1_default", "frag_l1_fill"):
+for n in ("fetch_default", "write_default", "fetch_fill", "write_fill", "frag_fetch_default", "frag_write_default", "frag_fetch_fill", "frag_write_fill", "frag_l1_default", "frag_l1_fill"):
     copy(f"pmc_{n}.csv", f"pmc_{n}.csv")
 for n in ("ranks.log", "rank_timeline.log", "top_items.log", "rank_frames.log", "rank0_stitch.log", "cold.log", "fragment.log", "parity_soak.log"):
     copy(n, n)
@@ -68,21 +68,42 @@ for n in ("phase_cycles.log", "gantt.log", "rank_sq_counters.txt", "line_loops.l
         copy(n, n)
 open(os.path.join(P, f"{prefix}_pytest_gpu.log"), "w").write("".join(open(os.path.join(G, "pytest_gpu.log")).readlines()[-3:]))
 
-# ---- SQ utilisation (default camera) ------------------------------------------------------------------------------------
-sq = {}
-lines = []
-for n in ("sq_a", "sq_b"):
-    pk = per_kernel(os.path.join(G, f"pmc_{n}.csv"))
-    # the frame's main launch exists with and without line groups (round 4; the handle probes both for a few frames): the one that drew most frames
-    mains = [k for k in LAUNCHES if k.startswith("vf::k_tile<false, false")]
-    main = max(mains, key=lambda k: LAUNCHES[k]) if mains else ""
-    lines.append(f"pmc_{n}.csv (averages per launch; main tile kernel of the run: {main}, {LAUNCHES.get(main, 0)} launches)")
-    for (kern, ctr), v in sorted(pk.items()):
-        if "k_tile" in kern or "k_block_setup" in kern:
-            lines.append(f"  {kern:34s} {ctr:26s} {v:16.0f}   ({LAUNCHES[kern]} launches)")
-        if kern == main:
-            sq[ctr] = v
-open(os.path.join(P, f"{prefix}_sq_counters.txt"), "w").write("\n".join(lines) + "\n")
+# ---- SQ utilisation: default camera, and (round 6) the top-down camera and the C5 orbit -----------------------------------
+def sq_passes(suffix):
+    sq, lines = {}, []
+    for n in ("sq_a", "sq_b"):
+        path = os.path.join(G, f"pmc_{n}{suffix}.csv")
+        if not os.path.exists(path):
+            return {}, []
+        pk = per_kernel(path)
+        # the frame's main launch exists with and without line groups (round 4; the handle probes both for a few frames): the one that drew most frames
+        mains = [k for k in LAUNCHES if k.startswith("vf::k_tile<false, false")]
+        main = max(mains, key=lambda k: LAUNCHES[k]) if mains else ""
+        lines.append(f"pmc_{n}{suffix}.csv (averages per launch; main tile kernel of the run: {main}, {LAUNCHES.get(main, 0)} launches)")
+        for (kern, ctr), v in sorted(pk.items()):
+            if "k_tile" in kern or "k_block_setup" in kern:
+                lines.append(f"  {kern:34s} {ctr:26s} {v:16.0f}   ({LAUNCHES[kern]} launches)")
+            if kern == main:
+                sq[ctr] = v
+    return sq, lines
+
+
+def sq_block(sq, what):
+    return {
+        "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
+        "valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq["SQ_INSTS_SALU"], "lds_wave_insts": sq["SQ_INSTS_LDS"],
+        "active_lanes_per_valu_inst": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+        "wave_cycles_active_wait_stall": [sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                                          sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]],
+        "note": f"k_tile fast variant, {what}; busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs) -- the counter ticks in quad-cycles, "
+                f"one per instruction at least, so this is an upper bound of the issue utilisation; passes {prefix}_sq_counters.txt",
+    }
+
+
+sq, lines = sq_passes("")
+sq_fill, lines_fill = sq_passes("_fill")
+sq_c5, lines_c5 = sq_passes("_c5")
+open(os.path.join(P, f"{prefix}_sq_counters.txt"), "w").write("\n".join(lines + lines_fill + lines_c5) + "\n")
 
 path = os.path.join(P, "pmc_traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
@@ -116,16 +137,32 @@ for cam in ("default", "fill"):
         "hbm_bytes_per_frame_all_kernels": int((2 * sum(f.get(k, 0.0) for k in frame) + sum(w.get(k, 0.0) for k in frame)) * 1024),
     }
     if cam == "default" and sq:
-        entry["sq"] = {
-            "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
-            "valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq["SQ_INSTS_SALU"], "lds_wave_insts": sq["SQ_INSTS_LDS"],
-            "active_lanes_per_valu_inst": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
-            "wave_cycles_active_wait_stall": [sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                                              sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]],
-            "note": f"k_tile fast variant; busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs) -- the counter ticks in quad-cycles, "
-                    f"one per instruction at least, so this is an upper bound of the issue utilisation; passes {prefix}_sq_counters.txt",
-        }
+        entry["sq"] = sq_block(sq, "default camera")
+    if cam == "fill" and sq_fill:
+        entry["sq"] = sq_block(sq_fill, "top-down camera")
     data[f"4096x4096_g4096_{cam}_n1"] = entry
+
+# ---- C5 (1920x1080, grid 2048, the 64-pose orbit through one batch call): traffic and SQ, per pose (= per tile-kernel launch) -------
+if os.path.exists(os.path.join(G, "pmc_fetch_c5.csv")) and os.path.exists(os.path.join(G, "pmc_write_c5.csv")):
+    f = per_kernel(os.path.join(G, "pmc_fetch_c5.csv")); lf = dict(LAUNCHES)
+    w = per_kernel(os.path.join(G, "pmc_write_c5.csv")); lw = dict(LAUNCHES)
+
+    def fold_c5(d, ctr, launches):
+        mains = [k for k in launches if k.startswith("vf::k_tile<false, false")]
+        main = max(mains, key=lambda k: launches[k]) if mains else None
+        out = collections.defaultdict(float)
+        for (k, c), v in d.items():
+            if c == ctr and not (k.startswith("vf::k_tile<false, false") and k != main):
+                out["vf::k_tile" if k.startswith("vf::k_tile<false") else k] += v
+        return out
+    f, w = fold_c5(f, "FETCH_SIZE", lf), fold_c5(w, "WRITE_SIZE", lw)
+    entry = {"tag": prefix, "lib_sha256": lib_hash, "k_tile": {"FETCH_SIZE_KiB": f.get("vf::k_tile", 0.0), "WRITE_SIZE_KiB": w.get("vf::k_tile", 0.0)},
+             "hbm_bytes_per_launch": int((2 * f.get("vf::k_tile", 0.0) + w.get("vf::k_tile", 0.0)) * 1024),
+             "hbm_bytes_per_launch_fetch_uncorrected": int((f.get("vf::k_tile", 0.0) + w.get("vf::k_tile", 0.0)) * 1024),
+             "note": "averages over the launches of the run: the orbit's poses differ"}
+    if sq_c5:
+        entry["sq"] = sq_block(sq_c5, "C5 orbit, average pose")
+    data["1920x1080_g2048_orbit_n1"] = entry
 
 # ---- the fragment stage on its own (k_resolve4): measured traffic per camera next to the algorithmic bytes -----------------
 for cam in ("default", "fill"):

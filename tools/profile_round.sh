@@ -30,6 +30,16 @@ pmc fetch_fill "FETCH_SIZE" $B --camera fill || exit 1
 pmc write_fill "WRITE_SIZE" $B --camera fill || exit 1
 pmc sq_a "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS" $B || exit 1
 pmc sq_b "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" $B || exit 1
+# round 6: the same two passes for the top-down camera (the slowest configuration) and the C5 orbit, plus their traffic
+SQA="SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS"
+SQB="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA"
+pmc sq_a_fill "$SQA" $B --camera fill || exit 1
+pmc sq_b_fill "$SQB" $B --camera fill || exit 1
+C5="$R/bench.py --workload c5 --steps 64 --warmup 8 --no-cpu-baseline --no-extra"
+pmc sq_a_c5 "$SQA" $C5 || exit 1
+pmc sq_b_c5 "$SQB" $C5 || exit 1
+pmc fetch_c5 "FETCH_SIZE" $C5 || exit 1
+pmc write_c5 "WRITE_SIZE" $C5 || exit 1
 for cam in default fill; do      # the fragment stage alone (k_resolve4), one camera per pass
   pmc frag_fetch_$cam "FETCH_SIZE" "$R/tools/exp_fragment.py" $cam || exit 1
   pmc frag_write_$cam "WRITE_SIZE" "$R/tools/exp_fragment.py" $cam || exit 1

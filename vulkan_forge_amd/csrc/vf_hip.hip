@@ -289,6 +289,18 @@ struct vf_terrain {
     } pre;
     uint64_t last_drawn_gen = 0;         // inputs_gen of the frame drawn last (two frames of one generation: the camera is at rest)
     bool replan_fresh = false;           // a plan queued ahead was thrown away: the next plan takes the previous frame's tile times (drop_preplan)
+    // Round 6: a caller that WAITS for every frame (every call of the reference's API) never makes the context's two plan streams (17-20 ms
+    // once per process, which its second call used to pay): its plans run on its own stream, and the plan made ahead for a camera at
+    // rest is queued BEHIND THE NEXT READ-BACK'S COPY (flush_preplan) -- it runs while the host unpacks / deflates / returns, not in
+    // front of the copy the caller waits for.  The plan streams are made when a frame arrives while the previous one is still in
+    // flight: a caller that streams frames, which is what they are for.
+    bool preplan_pending = false;
+    // ... unless that caller comes back faster than the plan runs: a tight loop of synchronous frames with nothing between them finds
+    // the plan made ahead still running behind the copy (C4 render_rgba 2.0 -> 2.2 ms, C2 0.10 -> 0.14), where the plan streams would
+    // have run it UNDER the frame.  Three such calls in a row and the handle takes the plan streams after all (17-20 ms, once).
+    uint32_t tight_calls = 0;
+    bool want_plan_streams = false;
+    hipEvent_t copied = nullptr;         // behind a read-back's copy: the host waits for this, not for the stream (the plan made ahead follows it)
     uint32_t *d_tile_map = nullptr;      // tile shards: local tile -> tx | ty << 16
     uint8_t *d_stripe_owner = nullptr;   // tile shards with a registered stripe map: owner per column stripe (kMaxStripes bytes)
     bool use_map = false;
@@ -470,8 +482,9 @@ static hipError_t sync_sides(const vf_terrain *t)            // (the side stream
 
 // A plan queued ahead of its frame (vf_terrain::pre) is thrown away: back to where the handle stood before it, and that set's segment list
 // starts empty again (the stale k_block_boxes filled it; its k_clear, which would have emptied it, never runs).
-static hipError_t drop_preplan(vf_terrain *t)
+static hipError_t drop_preplan(vf_terrain *t, hipStream_t next_plan_on = nullptr)
 {
+    t->preplan_pending = false;
     if (!t->pre.valid) return hipSuccess;
     const vf_terrain::PrePlan &R = t->pre;
     t->pre.valid = false;
@@ -481,11 +494,13 @@ static hipError_t drop_preplan(vf_terrain *t)
     // The stale plan's k_plan_sort has already zeroed this set's tile times and replaced its flag words: the frame that is planned in
     // its place reads the PREVIOUS frame's (complete: the caller was idle when the plan went out) -- plan_frame's `fresh` mode.
     t->replan_fresh = true;
-    if (!t->side) return hipSuccess;
-    // The stale chain ran on `side`, the stale set-up pass on `side2`: the frame planned next rewrites this set's block boxes, records
-    // and segment list from `side`, and must not do so while the stale set-up pass still reads and writes them.
-    hipError_t e = hipStreamWaitEvent(t->side, t->ps[R.K.set].set_up, 0);
-    if (e == hipSuccess) e = hipMemsetAsync(R.K.seg_count, 0, sizeof(uint32_t), t->side);
+    // The stale chain ran on `side`, the stale set-up pass on `side2` (a waiting caller's: both on the stream of its last read-back):
+    // the frame planned next rewrites this set's block boxes, records and segment list, and must not do so while the stale set-up pass
+    // still reads and writes them -- the stream its plan starts on waits for both.
+    hipStream_t on = t->side ? t->side : (next_plan_on ? next_plan_on : (t->last_stream ? t->last_stream : t->ctx->stream));
+    hipError_t e = hipStreamWaitEvent(on, t->ps[R.K.set].set_up, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(on, t->ps[R.K.set].planned, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(R.K.seg_count, 0, sizeof(uint32_t), on);
     return e;
 }
 
@@ -623,6 +638,7 @@ void vf_terrain_destroy(vf_terrain *t)
     pinned_free(t->h_png);
     for (auto &f : t->ev) for (auto &e : f) if (e) (void)hipEventDestroy(e);
     if (t->entry) (void)hipEventDestroy(t->entry);
+    if (t->copied) (void)hipEventDestroy(t->copied);
     for (auto &g : t->gprobe) { if (g.a) (void)hipEventDestroy(g.a); if (g.b) (void)hipEventDestroy(g.b); }
     delete t;
 }
@@ -1044,7 +1060,7 @@ static bool fast_shading(const vf_terrain *t) { return t->precision == VF_PRECIS
 // side streams (a handle's first frame: on `s`); it touches plan state only.  draw_frame: the kernels on the caller's stream.  What the
 // second half needs of the first travels in a FramePlan, so that the first half of the NEXT frame can be queued ahead of its call
 // (vf_terrain::pre, render_impl).
-static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = false)
+static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = false, bool streaming = false)
 {
     FrameParams &P = K.P;
     build_params(t, P);
@@ -1056,10 +1072,14 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = f
     // A handle's FIRST frame runs on the caller's stream alone, plan and set-up included: its chain is serial anyway (the static plan
     // estimate reads the set-up pass's records) and there is no earlier frame to hide anything under.  The side streams and the second
     // plan chain's events come into play with the second frame.
-    const bool solo = !t->side && t->frame_no == 1u;
-    if (!solo && !t->side) {
-        VF_HIP_TRY(ctx_side_streams(t->ctx, &t->side, &t->side2));   // (borrowed from the context: made once per process)
+    // ... and so do the frames of a caller that waits for each of them (round 6): the plan streams are made for the caller that
+    // streams -- a frame arriving while the previous one is in flight -- or borrowed when the context already has them.
+    if (!t->side && t->frame_no > 1u) {
+        bool have = false;
+        { std::lock_guard<std::mutex> lk(t->ctx->lazy_mu); have = t->ctx->side && t->ctx->side2; }
+        if (have || streaming || t->want_plan_streams) VF_HIP_TRY(ctx_side_streams(t->ctx, &t->side, &t->side2));   // (the context's: made once per process)
     }
+    const bool solo = !t->side;
     VF_HIP_TRY(ensure_plan_state(t, set, solo ? s : t->side));
     vf_terrain::PlanState &S = t->ps[set], &O = t->ps[t->last_set];       // this frame's plan state, the previous frame's
     // A camera at rest (or moving slowly) plans under the previous frame's tile kernel with the feedback of the frame before it;
@@ -1294,6 +1314,42 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
     return VF_OK;
 }
 
+// The first half of the NEXT frame, queued ahead of its call (vf_terrain::pre).
+static void plan_ahead(vf_terrain *t, hipStream_t s)
+{
+    vf_terrain::PrePlan &R = t->pre;
+    R.cur_set = t->cur_set; R.frame_no = t->frame_no; R.frames_since_reset = t->frames_since_reset;
+    R.camera_moving = t->camera_moving; R.was_moving = t->was_moving; R.have_drawn = t->have_drawn;
+    std::memcpy(R.u_drawn, t->u_drawn, sizeof R.u_drawn);
+    if (plan_frame(t, s, R.K, true) == VF_OK) { R.valid = true; R.gen = t->inputs_gen; }
+    else {                                                  // (a failed launch: the next call plans for itself and reports it)
+        t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
+        (void)hipGetLastError();
+    }
+}
+
+// A read-back has queued its copy on `s`: the plan a waiting caller's next frame will want goes out now, behind the copy (the caller
+// waits for the copy's event, not for the stream), if the frame was drawn from inputs that still stand.
+static void flush_preplan(vf_terrain *t, hipStream_t s)
+{
+    if (!t->preplan_pending) return;
+    t->preplan_pending = false;
+    if (t->pre.valid || t->side || t->last_drawn_gen != t->inputs_gen || t->bounds_dirty || s != t->last_stream) return;
+    plan_ahead(t, s);
+}
+
+// ... and the wait that goes with it: for the copy's event when a plan was queued behind it, for the stream otherwise
+static hipError_t finish_readback(vf_terrain *t, hipStream_t s)
+{
+    if (!t->preplan_pending) return hipStreamSynchronize(s);
+    hipError_t e = t->copied ? hipSuccess : hipEventCreateWithFlags(&t->copied, hipEventDisableTiming);
+    if (e != hipSuccess) { t->preplan_pending = false; return hipStreamSynchronize(s); }
+    e = hipEventRecord(t->copied, s);
+    if (e != hipSuccess) return e;
+    flush_preplan(t, s);
+    return hipEventSynchronize(t->copied);
+}
+
 static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
 {
     FramePlan K;
@@ -1303,27 +1359,31 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     // plan itself, at the same moment, and a plan queued ahead would only be one more after the last frame.
     const bool idle_at_entry = t->rendered && hipEventQuery(t->ps[t->last_set].drawn) == hipSuccess;
     (void)hipGetLastError();                                // ("not ready" is not an error)
+    const bool streaming = t->rendered && !idle_at_entry;
+    t->preplan_pending = false;                             // (no read-back came in between: this call plans for itself)
     if (t->pre.valid) {
         t->pre.valid = false;
-        if (t->pre.gen == t->inputs_gen && !write_vis) { K = t->pre.K; planned = true; }
-        else { t->pre.valid = true; VF_HIP_TRY(drop_preplan(t)); }     // made for other inputs
+        if (t->pre.gen == t->inputs_gen && !write_vis) {
+            K = t->pre.K; planned = true;
+            if (!t->side) {                                 // a waiting caller's plan, queued behind its last read-back: done by now?
+                const bool ready = hipEventQuery(t->ps[K.set].planned) == hipSuccess;
+                (void)hipGetLastError();
+                t->tight_calls = ready ? 0u : t->tight_calls + 1u;
+                if (t->tight_calls >= 3u) t->want_plan_streams = true;
+            }
+        }
+        else { t->pre.valid = true; VF_HIP_TRY(drop_preplan(t, s)); }     // made for other inputs
     }
-    if (!planned) { const int rc = plan_frame(t, s, K); if (rc != VF_OK) return rc; }
+    if (!planned) { const int rc = plan_frame(t, s, K, false, streaming); if (rc != VF_OK) return rc; }
     const bool again = t->last_drawn_gen == t->inputs_gen;      // the frame before this one was drawn from the same inputs
     const int rc = draw_frame(t, s, K, write_vis);
     if (rc != VF_OK) return rc;
     t->last_drawn_gen = t->inputs_gen;
     // the camera is at rest (two frames from one set of inputs), the handle is past its first frames, nothing diagnostic is going on:
     // the next frame's plan goes out now
-    if (again && idle_at_entry && !write_vis && t->side && !t->bounds_dirty && !t->camera_moving && !t->was_moving && t->frames_since_reset > vf_terrain::kPlanStates && !(t->timing && t->stats_on)) {
-        vf_terrain::PrePlan &R = t->pre;
-        R.cur_set = t->cur_set; R.frame_no = t->frame_no; R.frames_since_reset = t->frames_since_reset;
-        R.camera_moving = t->camera_moving; R.was_moving = t->was_moving; R.have_drawn = t->have_drawn;
-        std::memcpy(R.u_drawn, t->u_drawn, sizeof R.u_drawn);
-        if (plan_frame(t, s, R.K, true) == VF_OK) { R.valid = true; R.gen = t->inputs_gen; }
-        else {                                              // (a failed launch: the next call plans for itself and reports it)
-            t->cur_set = R.cur_set; t->frame_no = R.frame_no; t->frames_since_reset = R.frames_since_reset;
-        }
+    if (again && idle_at_entry && !write_vis && !t->bounds_dirty && !t->camera_moving && !t->was_moving && t->frames_since_reset > vf_terrain::kPlanStates && !(t->timing && t->stats_on)) {
+        if (t->side) plan_ahead(t, s);                      // on the plan streams, under this frame's tile kernel
+        else t->preplan_pending = true;                     // no plan streams (a waiting caller): behind the next read-back's copy, flush_preplan
     }
     return VF_OK;
 }
@@ -1479,8 +1539,8 @@ static hipError_t copy_to_pinned(void *host, const void *dev, size_t n, hipStrea
 static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, size_t n, hipStream_t s)
 {
     // a destination in pinned host memory (vf_host_alloc, or the caller's own hipHostMalloc / hipHostRegister): one transfer, nothing to stage
-    if (is_pinned_host(dst)) { VF_HIP_TRY(copy_to_pinned(dst, src, n, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
-    if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(hipStreamSynchronize(s)); return VF_OK; }
+    if (is_pinned_host(dst)) { VF_HIP_TRY(copy_to_pinned(dst, src, n, s)); VF_HIP_TRY(finish_readback(t, s)); return VF_OK; }
+    if (n < kStageChunk) { VF_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); VF_HIP_TRY(finish_readback(t, s)); return VF_OK; }
     if (!t->h_stage) VF_HIP_TRY(pinned_alloc((void **)&t->h_stage, kStageSlots * kStageChunk));
     for (auto &e : t->stage_ev) if (!e) VF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t nchunks = (n + kStageChunk - 1) / kStageChunk;
@@ -1518,6 +1578,7 @@ static int copy_to_host_staged(vf_terrain *t, uint8_t *dst, const uint8_t *src, 
         if (err == hipSuccess) err = hipEventRecord(t->stage_ev[i % kStageSlots], s);
         if (err == hipSuccess) enqueued.store(i + 1, std::memory_order_release);
     }
+    if (err == hipSuccess) flush_preplan(t, s);            // (behind the last chunk's copy: the threads above wait for the chunks' events)
     if (err != hipSuccess) failed.store(1);
     for (auto &th : pool) th.join();
     if (err != hipSuccess) return fail(VF_ERR_HIP, hipGetErrorString(err));
@@ -1563,7 +1624,7 @@ int vf_terrain_read_png_scanlines(vf_terrain *t, const uint8_t **host_scanlines,
     if (!t->h_png) VF_HIP_TRY(pinned_alloc((void **)&t->h_png, n));
     uint8_t *host = t->h_png;
     VF_HIP_TRY(copy_to_pinned(host, t->d_png, n, s));
-    VF_HIP_TRY(hipStreamSynchronize(s));
+    VF_HIP_TRY(finish_readback(t, s));                      // (a waiting caller's next plan runs while the host deflates)
     *host_scanlines = host;
     *nbytes = n;
     return VF_OK;

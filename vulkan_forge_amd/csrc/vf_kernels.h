@@ -484,7 +484,7 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // (owned by a higher block row) are skipped unsolved, and only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
 #ifdef VF_PHASE_PROF
-struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach; };
+struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach, l_iter; };   // w_*: wave-level executions, the others lane-level: their ratio is the lanes a wave keeps busy there
 #define VF_RC_ARG , RasterCounts &RC
 #define VF_RC(...) __VA_ARGS__
 #else
@@ -555,7 +555,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
             span_group(S, oa, ob, n_inner, glo, ghi);
             if (!S.regular) { glo = 0; ghi = n_inner; }
             open = glo <= ghi && (bit_range(i_base + min(glo, n_inner), i_base + max(ghi, 0)) & ~done4) != 0ull;
-            VF_RC(RC.lines += (uint32_t)(ob - oa + 1);)
+            VF_RC(RC.lines += (uint32_t)(ob - oa + 1); RC.l_iter++;)
         }
         VF_RC(if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;)
         const unsigned long long votes = __ballot(open);
@@ -574,7 +574,7 @@ __device__ __forceinline__ void raster_fast(const TileCtx &T, uint32_t word, con
             if (o < 0 || o > n_outer) continue;
         }
         const uint64_t done = load_mask(fin, o_base + o);
-        if constexpr (!GROUPS) { VF_RC(RC.lines++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;) }
+        if constexpr (!GROUPS) { VF_RC(RC.lines++; RC.l_iter++; if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) RC.w_iter++;) }
         // ---- stage 1 (straight-line): a span that contains the true one; does it hold an open pixel? ----
         int32_t F[3], lo, hi;
         span_line(S, o, n_inner, F, lo, hi);
@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     VF_PH_INIT
-    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0;)
+    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0, rc_alive = 0, rc_apass = 0, rc_act = 0;)
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < kLutFloats; k += kTileThreads) s_lut[k] = lut_linear[k];
@@ -1868,7 +1868,7 @@ next_item:
                     nsurv += (uint32_t)__popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
-                VF_RC(if (lane == 0) { rc_nsurv += nsurv; rc_live++; rc_empty += nsurv ? 0u : 1u; })
+                VF_RC(if (lane == 0) { rc_nsurv += nsurv; rc_live++; rc_empty += nsurv ? 0u : 1u; rc_alive += n_alive; rc_apass += (n_alive + 63u) / 64u; })
                 VF_PH(3)
                 // ---- pass B: the survivors share the wave: with few of them, 2..64 lanes split the lines of one triangle ----
                 {
@@ -1913,9 +1913,9 @@ next_item:
                         }
                     }
                     for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {      // (balanced: one round)
-                        VF_RC(if (lane == 0) rc_iters++;)
                         const uint32_t sidx = sbase + q;
                         const bool act = balanced ? lane < b_used : (q < group && sidx < nsurv);
+                        VF_RC({ const uint32_t na = (uint32_t)__popcll(__ballot(act)); if (lane == 0) { rc_iters++; rc_act += na; } })
                         if (act) {
                             const uint32_t code = balanced ? (b_mine & 0xFFu) : (uint32_t)sS[wave][sidx];
                             const uint32_t my_sub = balanced ? lane - ((b_mine >> 8) & 0xFFu) : sub, my_n = balanced ? b_mine >> 16 : per;
@@ -2058,6 +2058,12 @@ next_item:
             atomicAdd(&ph[32], (unsigned long long)ph_acc[18]); atomicAdd(&ph[33], (unsigned long long)ph_acc[19]);
             atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
             atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
+            atomicAdd(&ph[35], (unsigned long long)rc_alive); atomicAdd(&ph[36], (unsigned long long)rc_apass); atomicAdd(&ph[37], (unsigned long long)rc_act);
+        }
+        {   // lanes in the line loop's first step (group tests with line groups, line trips without)
+            uint32_t li = RC.l_iter;
+            for (int o = 32; o > 0; o >>= 1) li += __shfl_xor(li, o);
+            if (lane == 0) atomicAdd(&ph[34], (unsigned long long)li);
         }
         uint32_t rcs[4] = { RC.lines, RC.solved, RC.painted, RC.trips };   // (paint_lines gave way to: lines with an open pixel in their bounding range)
         for (int c = 0; c < 4; ++c) {

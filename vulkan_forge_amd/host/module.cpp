@@ -106,18 +106,23 @@ public:
         { std::lock_guard<std::mutex> lk(mu); made_bytes += bytes; }
         return p;
     }
-    // ... for a caller that can do without: nullptr once kMaxOutBytes of page-locked memory are out with arrays the caller keeps
-    // (page-locked memory cannot be swapped: a loop that keeps every frame gets ordinary arrays beyond that)
-    void *take_or_null(size_t bytes)
+    // ... for a caller that can do without: nullptr once `max_out` bytes of page-locked memory are out with arrays the caller keeps.
+    // render_rgba allows three frames (round 6): a loop that DROPS its frames alternates between two pooled buffers for good, a loop
+    // that KEEPS them gets ordinary arrays from the fourth on -- filled through the handle's ring of pinned chunks by four host threads,
+    // 2.1 ms for a C4 frame, where a page-locked buffer of its own per frame costs 2.6 ms to make on top of the 1.3 ms transfer (round
+    // 5: 4.9 ms per kept frame) and cannot be swapped.  render_batch allows kMaxOutBytes.
+    void *take_or_null(size_t bytes, size_t max_out)
     {
         {
             std::lock_guard<std::mutex> lk(mu);
             bool have = false;
-            for (auto &b : idle) have |= b.second == bytes;
-            if (!have && made_bytes + bytes > kMaxOutBytes) return nullptr;
+            size_t held = 0;
+            for (auto &b : idle) { have |= b.second == bytes; held += b.second; }
+            if (!have && (made_bytes - held) + bytes > max_out) return nullptr;
         }
         return take(bytes);
     }
+    static constexpr size_t kMaxOutBytes = (size_t)1 << 30;
     void give(void *p, size_t bytes)
     {
         std::vector<void *> drop;
@@ -131,7 +136,7 @@ public:
         for (void *d : drop) vf_host_free(d);
     }
 private:
-    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30, kMaxOutBytes = (size_t)4 << 30;
+    static constexpr size_t kMaxIdle = 4, kMaxIdleBytes = (size_t)1 << 30;
     size_t made_bytes = 0;                                      // page-locked and not freed: idle buffers + those out with arrays
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> idle;
@@ -287,7 +292,7 @@ public:
             return a;
         }
         // frame-sized: the array lives in page-locked memory from the pool (above) -- one DMA transfer, no host copy
-        void *p = PinnedPool::get().take_or_null(bytes);
+        void *p = PinnedPool::get().take_or_null(bytes, 3 * bytes);
         if (!p) {                                                // (the caller keeps its frames: ordinary arrays from here on)
             py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
             render_into(a.mutable_data(), rows);
@@ -326,20 +331,49 @@ public:
         }
         if (n == 0) return files.empty() && paths.is_none() ? py::object(py::list()) : py::object(py::none());
         const size_t bytes = (size_t)H * W * 4;
-        std::vector<py::capsule> owners;
+        view = v; proj = p;                                     // the camera of the last pose stays, as after a loop of set_camera_look_at
+        if (!files.empty()) {
+            // PNG files: the poses go through in groups over a few pooled page-locked buffers -- every group one batch call, its frames
+            // encoded before the next group is drawn -- so the page-locked footprint is kGroup frames whatever the number of poses
+            // (advisor, round 5: n buffers up front were 4 GiB of unswappable memory and n registrations for 64 poses at 4096^2)
+            constexpr size_t kGroup = 4;
+            std::vector<py::capsule> owners;
+            std::vector<uint8_t *> dst;
+            for (size_t k = 0; k < std::min(n, kGroup); ++k) { void *q = PinnedPool::get().take(bytes); owners.push_back(pinned_owner(q, bytes)); dst.push_back(static_cast<uint8_t *>(q)); }
+            {
+                py::gil_scoped_release nogil;
+                for (size_t k0 = 0; k0 < n; k0 += kGroup) {
+                    const size_t m = std::min(kGroup, n - k0);
+                    const int rc = vf_terrain_render_batch_host(t, blocks.data() + 44 * k0, (uint32_t)m, dst.data());
+                    if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
+                    for (size_t k = 0; k < m; ++k) write_png_rgba8(files[k0 + k], dst[k], W, H);
+                }
+            }
+            push_uniforms();
+            return py::none();
+        }
+        // arrays: page-locked while the pool's allowance lasts (one DMA each, beside the next poses' kernels), ordinary memory beyond
+        // (the runtime stages those copies: correct, slower)
+        py::list frames;
         std::vector<uint8_t *> dst(n);
-        for (size_t k = 0; k < n; ++k) { void *q = PinnedPool::get().take(bytes); owners.push_back(pinned_owner(q, bytes)); dst[k] = static_cast<uint8_t *>(q); }
+        for (size_t k = 0; k < n; ++k) {
+            void *q = bytes >= ((size_t)4 << 20) ? PinnedPool::get().take_or_null(bytes, PinnedPool::kMaxOutBytes) : nullptr;
+            if (q) {
+                py::capsule owner = pinned_owner(q, bytes);
+                frames.append(py::array_t<uint8_t>({ (py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)4 }, static_cast<uint8_t *>(q), owner));
+                dst[k] = static_cast<uint8_t *>(q);
+            } else {
+                py::array_t<uint8_t> a({ (py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)4 });
+                dst[k] = a.mutable_data();
+                frames.append(a);
+            }
+        }
         {
             py::gil_scoped_release nogil;
             const int rc = vf_terrain_render_batch_host(t, blocks.data(), (uint32_t)n, dst.data());
             if (rc != VF_OK) { py::gil_scoped_acquire gil; raise_vf(rc); }
-            for (size_t k = 0; k < files.size(); ++k) write_png_rgba8(files[k], dst[k], W, H);
         }
-        view = v; proj = p;                                     // the camera of the last pose stays, as after a loop of set_camera_look_at
         push_uniforms();
-        if (!files.empty()) return py::none();
-        py::list frames;
-        for (size_t k = 0; k < n; ++k) frames.append(py::array_t<uint8_t>({ (py::ssize_t)H, (py::ssize_t)W, (py::ssize_t)4 }, dst[k], owners[k]));
         return frames;
     }
     // extension: visible primitive id + 1 per pixel of the last render (0 = background)
