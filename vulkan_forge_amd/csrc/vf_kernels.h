@@ -484,7 +484,7 @@ __device__ __forceinline__ uint64_t bit_range(int32_t lo, int32_t hi)   // bits 
 // (owned by a higher block row) are skipped unsolved, and only non-final pixels are touched.
 // `sub` / `nsub`: the lines of one triangle are dealt round-robin to nsub cooperating lanes (all of them run the set-up).
 #ifdef VF_PHASE_PROF
-struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach, l_iter; };   // w_*: wave-level executions, the others lane-level: their ratio is the lanes a wave keeps busy there
+struct RasterCounts { uint32_t tris, lines, solved, painted, paint_lines, trips, w_iter, w_s1, w_s2, w_paint, w_cls, c_reach, l_iter, nsurv, iters, live, empty, alive, apass, act; };   // w_*: wave-level executions, the others lane-level: their ratio is the lanes a wave keeps busy there
 #define VF_RC_ARG , RasterCounts &RC
 #define VF_RC(...) __VA_ARGS__
 #else
@@ -1441,12 +1441,310 @@ __global__ __launch_bounds__(256) void k_plan_sort(const uint2 *__restrict__ wor
 //      conservative); a fully final tile stops early;
 //   5. fragment stage on the LDS tile.
 #ifdef VF_PHASE_PROF   // diagnostics build: per-phase shader-clock cycles and event counts (vf_terrain_debug_phase_cycles)
-#define VF_PH_INIT uint64_t ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t ph_last = __builtin_readcyclecounter();   // 8..15: parts of the set-up; 16, 17: parts of `vertex`
-#define VF_PH(p) { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[p] += ph_now - ph_last; ph_last = ph_now; }
+struct PhaseClock {
+    uint64_t acc[20], last;                                // 8..15: parts of the set-up; 16..19: parts of `vertex`
+    __device__ __forceinline__ void start() { for (int k = 0; k < 20; ++k) acc[k] = 0; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void tick(int p) { const uint64_t now = __builtin_readcyclecounter(); acc[p] += now - last; last = now; }
+};
+#define VF_PH_INIT PhaseClock PH; PH.start();
+#define VF_PH(p) PH.tick(p);
+#define VF_PH_ARG , PhaseClock &PH
+#define VF_PH_PASS , PH
 #else
 #define VF_PH_INIT
 #define VF_PH(p)
+#define VF_PH_ARG
+#define VF_PH_PASS
 #endif
+// ---- k_tile's constants, its LDS and its phases --------------------------------------------------------------------------------
+namespace tile {
+constexpr int kWaves = kTileThreads / 64;
+constexpr int kNV = kBlockVerts * kBlockVerts;             // 81
+constexpr uint32_t kChunk = 4096;                          // work-list entries per chunk (>= one full block row: nb <= 1024)
+constexpr int kMaxSteps = 128;                             // block rows per chunk
+constexpr int kHitWords = 16;                              // 64-bit ballots per block row (nb <= 1024)
+constexpr int kRescanEvery = 1;                            // publish new masks when the frontier moved this many steps
+constexpr int kBlockPrims = 2 * kBlockCells * kBlockCells;
+constexpr uint32_t kWideLines = 28, kBalGain = 2;          // lane dealing by line counts: looked at when a survivor has more lines than this / taken when it saves this many trips
+// The waves' private arrays of the block loop share their LDS with the ballots of the list building (`hit`): the ballots are dead
+// from the barrier behind the list fill to the barrier behind the block loop, the private arrays live only between the two.  The
+// kernel's LDS falls from 80.5 to 64 KB: two of its workgroups (this frame's last, the next frame's first) then leave a CU 32 KB for
+// the set-up pass that runs beside them, where they left 2.8 -- C4 -1.4 %, top-down camera -0.9 % (round 5; spent on chunks of 192
+// block rows instead, the 16 KB lose: 0.7189 -> 0.7239 ms).
+struct WaveLds {
+    int2 xy[kWaves][kNV];                                  // per wave: snapped vertices of the current block (from k_block_setup)
+    uint8_t alive[kWaves][kBlockPrims];                    // per wave: the block's alive primitives (cell << 1 | odd), compacted
+    uint8_t surv[kWaves][kBlockPrims];                     // per wave: those of them that survive against this tile
+    uint8_t lines[kWaves][kBlockPrims];                    // per wave: ... and how many lines each of them has inside the tile
+};
+constexpr size_t kHitBytes = sizeof(unsigned long long) * kMaxSteps * kHitWords;
+constexpr size_t kOverlayBytes = sizeof(WaveLds) > kHitBytes ? sizeof(WaveLds) : kHitBytes;
+// The workgroup's LDS as the phases below see it: pointers to the kernel's __shared__ arrays (every phase is inlined into the kernel,
+// where they ARE the arrays again -- one struct in LDS instead would cost the compiler the knowledge that the arrays do not overlap).
+struct Lds {
+    uint32_t *vis;                                         // the 64 x 64 visibility tile (rows skewed: vis_index)
+    unsigned long long (*hit)[kHitWords];                  // 64-bit ballots per block row of the chunk (list building)
+    int2 (*xy)[kNV]; uint8_t (*alive)[kBlockPrims]; uint8_t (*surv)[kBlockPrims]; uint8_t (*lines)[kBlockPrims];   // WaveLds (block loop)
+    uint32_t *list;                                        // bx | by << 10 | step << 20
+    uint32_t *cnt;                                         // candidates per step
+    uint16_t *words;                                       // per step: first | end << 8 of the 64-block groups its ballots were taken for
+    uint32_t *pending;                                     // blocks of the step not finished yet
+    uint32_t *firstid;
+    uint16_t *allrows;                                     // block rows that reach the tile, descending (nb <= 1024)
+    uint32_t *rc;                                          // per block row: first | end << 16 of the blocks that can reach this tile column
+    uint32_t *colfin, *rowfin, *colfin4, *rowfin4;         // final-pixel masks per line, per four lines (refresh_fin4)
+    uint32_t *part;
+    unsigned long long *rows;                              // bit r of word w: block row 64 w + r reaches this tile
+    uint32_t *next, *lock, *done, *frontier, *published, *blocks, *redo;
+    const uint32_t *per;                                   // [survivors]: lanes per survivor | ceil(2^16 / that) << 7 | survivors per round << 24
+};
+// (the frontier words are read while other waves write them: relaxed atomic loads on the LDS variables themselves -- a `volatile`
+//  pointer loses the address space, the loads become FLAT ones and their 64-bit generic addresses live in (spilled) vector registers)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// An item's block rows: those whose pixel box touches the tile (most tiles of a frame see none: background), as a bit mask and then
+// as a list, highest row first (= descending primitive id).  Returns their number.  Two workgroup barriers inside.
+__device__ __forceinline__ uint32_t list_block_rows(const FrameParams &P, const Lds &L, const TileCtx &T, const PixelBox *__restrict__ row_boxes,
+                                                    const uint32_t *__restrict__ rc_lo, const uint32_t *__restrict__ rc_hi, uint32_t tcol,
+                                                    uint32_t tid, uint32_t lane, uint32_t wave VF_PH_ARG)
+{
+    // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
+    for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
+        const uint32_t r = base + tid;
+        bool hit = false;
+        if (r < P.nb) {
+            const PixelBox rr = row_boxes[r];
+            const uint32_t lo = rc_lo[tcol * P.nb + r], hi = rc_hi[tcol * P.nb + r];
+            L.rc[r] = lo < hi ? lo | (hi << 16) : 1u;                  // (1 = the empty range [1, 0))
+            hit = lo < hi && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi && rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0 && m) L.rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
+    }
+    __syncthreads();
+    VF_PH(14)                                              // row mask
+
+    // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands words 15 - w, 15 - w - kWaves, ... ----
+    uint32_t nrows_total = 0;
+    {
+        uint32_t cnt[16];
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; ++w) { cnt[w] = (uint32_t)__popcll(L.rows[w]); nrows_total += cnt[w]; }
+        for (uint32_t word = 15u - wave; word < 16u; word -= (uint32_t)kWaves) {     // (unsigned wrap ends the loop)
+            uint32_t above = 0;                            // hit rows in the words above this one
+#pragma unroll
+            for (uint32_t w = 0; w < 16u; ++w) above += w > word ? cnt[w] : 0u;
+            const unsigned long long m = L.rows[word];
+            const uint32_t b = 63u - lane;                 // lane 0 takes the highest row of the word
+            if ((m >> b) & 1ull) L.allrows[above + (uint32_t)__popcll(b == 63u ? 0ull : m >> (b + 1u))] = (uint16_t)(word * 64u + b);
+        }
+    }
+    __syncthreads();
+
+    return nrows_total;
+}
+
+// A chunk's candidate tests for narrow strips (the kernel instantiation without line groups): which blocks of the chunk's rows can still
+// draw into the tile?  Ballots per row in `hit` (kept for the list fill), counts in `cnt`.
+// Lanes = (row, block) pairs: a row's range holds a dozen blocks in the far field and fewer elsewhere, so a wave takes EIGHT of
+// the chunk's rows at once, eight lanes each (round 4; before: four rows per pass, 64 lanes per row, ten of them busy -- two
+// passes, i.e. two memory round trips, and four times the instructions per chunk).  Two blocks per lane and trip are requested
+// together: the latency of the bounds -- the whole cost of this phase -- is paid once per sixteen blocks of a row.  Hits are
+// OR-ed into the row's ballot words (the list fill reads the same words as before: same list, same order).
+template <bool GROUPS>
+__device__ __forceinline__ void test_candidates_pairs(const FrameParams &P, const SetupView &V, const Lds &L, const TileCtx &T, const float4 *__restrict__ cap_seg,
+                                                      const float *__restrict__ cap_rad, uint32_t cursor, uint32_t nrowsteps, uint32_t lane, uint32_t wave)
+{
+    const uint32_t rsub = lane >> 3, bsub = lane & 7u;
+    uint32_t *const hit32 = reinterpret_cast<uint32_t *>(&L.hit[0][0]);
+    for (uint32_t kbase = 0; kbase < nrowsteps; kbase += 8u * kWaves) {            // (one trip for a chunk of <= 128 rows)
+        const uint32_t k = kbase + wave + rsub * kWaves;
+        const bool valid = k < nrowsteps;
+        uint32_t by = 0, lo = 1, hi = 0;
+        if (valid) { by = L.allrows[cursor + k]; const uint32_t range = L.rc[by]; lo = range & 0xFFFFu; hi = range >> 16; }
+        const uint32_t g_first = lo >> 6, g_last = lo < hi ? ((hi - 1u) >> 6) + 1u : g_first;
+        if (valid && bsub == 0u) for (uint32_t g = g_first; g < g_last; ++g) L.hit[k][g] = 0ull;
+        __builtin_amdgcn_wave_barrier();            // (LDS operations of one wave complete in order: the zeros are behind us)
+        uint32_t cnt = 0;
+        for (uint32_t b0 = lo + bsub; b0 < hi; b0 += 16u) {
+            const uint32_t b1 = b0 + 8u;
+            const bool in1 = b1 < hi;
+            const uint32_t i0 = by * P.nb + b0, i1 = by * P.nb + (in1 ? b1 : b0);
+            const PixelBox box0 = V.recs[i0].box, box1 = V.recs[i1].box;
+            const float4 seg0 = cap_seg[i0], seg1 = cap_seg[i1];
+            const float rad0 = cap_rad[i0], rad1 = cap_rad[i1];
+            if (block_is_candidate<GROUPS>(box0, seg0, rad0, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b0 >> 5)], 1u << (b0 & 31u)); ++cnt; }
+            if (in1 && block_is_candidate<GROUPS>(box1, seg1, rad1, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b1 >> 5)], 1u << (b1 & 31u)); ++cnt; }
+        }
+        // the row's eight lanes: quad, the other quad (DPP, no LDS round trips)
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror
+        // (the list fill reads the ballots of groups g_first .. g_last - 1 only: the others are never written)
+        if (valid && bsub == 0u) { L.cnt[k] = cnt; L.words[k] = (uint16_t)(g_first < g_last ? g_first | (g_last << 8) : 0u); L.firstid[k] = 2u * (by * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+    }
+}
+
+// ... and for wide items (the instantiation with line groups; its items have a dozen rows): lanes = the blocks of a row.
+// Four rows per pass: their bounds (pixel box, capsule) are fetched together, so the global-memory latency -- the
+// whole cost of this phase -- is paid once per pass instead of once per row and array.
+template <bool GROUPS>
+__device__ __forceinline__ void test_candidates_rows(const FrameParams &P, const SetupView &V, const Lds &L, const TileCtx &T, const float4 *__restrict__ cap_seg,
+                                                     const float *__restrict__ cap_rad, uint32_t cursor, uint32_t nrowsteps, uint32_t hit_words, uint32_t lane, uint32_t wave)
+{
+    constexpr int kRowsAtOnce = 4;
+    for (uint32_t k0 = wave; k0 < nrowsteps; k0 += kRowsAtOnce * kWaves) {
+        uint32_t by[kRowsAtOnce], bx_lo[kRowsAtOnce], bx_hi[kRowsAtOnce], cnt[kRowsAtOnce];
+#pragma unroll
+        for (int r = 0; r < kRowsAtOnce; ++r) {
+            const uint32_t k = k0 + (uint32_t)r * kWaves;
+            const bool valid = k < nrowsteps;
+            by[r] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.allrows[cursor + k]) : 0u;
+            // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
+            const uint32_t range = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rc[by[r]]) : 1u;
+            bx_lo[r] = range & 0xFFFFu;
+            bx_hi[r] = range >> 16;
+            cnt[r] = 0u;
+        }
+        uint32_t g_first = hit_words, g_last = 0;                 // groups of 64 blocks that hold any block of the four ranges
+#pragma unroll
+        for (int r = 0; r < kRowsAtOnce; ++r)
+            if (bx_lo[r] < bx_hi[r]) { g_first = min(g_first, bx_lo[r] >> 6); g_last = max(g_last, ((bx_hi[r] - 1u) >> 6) + 1u); }
+        for (uint32_t g = g_first; g < g_last; ++g) {
+            const uint32_t bx = g * 64u + lane;
+            PixelBox box[kRowsAtOnce];
+            float4 seg[kRowsAtOnce];
+            float rad[kRowsAtOnce];
+            bool in[kRowsAtOnce];
+#pragma unroll
+            for (int r = 0; r < kRowsAtOnce; ++r) {
+                in[r] = bx >= bx_lo[r] && bx < bx_hi[r];
+                box[r] = PixelBox{ 1, 1, 0, 0 }; seg[r] = make_float4(0.f, 0.f, 0.f, 0.f); rad[r] = 0.0f;
+                if (in[r]) {
+                    const uint32_t bidx = by[r] * P.nb + bx;
+                    box[r] = V.recs[bidx].box; seg[r] = cap_seg[bidx]; rad[r] = cap_rad[bidx];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRowsAtOnce; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * kWaves;
+                if (k >= nrowsteps) continue;                                   // uniform
+                const unsigned long long m = __ballot(in[r] && block_is_candidate<GROUPS>(box[r], seg[r], rad[r], T));
+                if (lane == 0) L.hit[k][g] = m;
+                cnt[r] += (uint32_t)__popcll(m);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kRowsAtOnce; ++r) {
+            const uint32_t k = k0 + (uint32_t)r * kWaves;
+            // (the list fill reads the ballots of groups g_first .. g_last - 1 only: the others are never written)
+            if (lane == 0 && k < nrowsteps) { L.cnt[k] = cnt[r]; L.words[k] = (uint16_t)(g_first < g_last ? g_first | (g_last << 8) : 0u); L.firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
+        }
+    }
+}
+
+// A chunk's work list from the kept ballots: how many of its rows fit the list (`nsteps`), how many blocks they hold (`nlist`).
+__device__ __forceinline__ void fill_work_list(const Lds &L, uint32_t cursor, uint32_t nrowsteps, uint32_t lane, uint32_t wave, uint32_t &nsteps, uint32_t &nlist)
+{
+    // ---- chunk set-up 2: every wave scans the row counts for itself (64 rows at a time, DPP), so all agree on the list offsets
+    //      and on how many rows fit the list without another barrier; rows that do not fit wait for the next chunk ----
+    constexpr int kParts = kMaxSteps / 64;              // the rows of a chunk, 64 (one per lane) at a time
+    static_assert(kMaxSteps % 64 == 0 && kParts >= 1 && kParts <= 4, "the offset scan below works on 64-row parts");
+    uint32_t c[kParts], inc[kParts];
+    unsigned long long fm[kParts];
+#pragma unroll
+    for (int p = 0; p < kParts; ++p) {
+        c[p] = lane + 64u * p < nrowsteps ? L.cnt[lane + 64u * p] : 0u;
+        inc[p] = wave_scan_add(c[p]);
+        if (p) inc[p] += (uint32_t)__builtin_amdgcn_readlane((int)inc[p - 1], 63);
+        fm[p] = __ballot(lane + 64u * p < nrowsteps && inc[p] <= kChunk);
+    }
+    // rows are admitted in order: stop at the first one that does not fit (a single row always fits: nb <= 1024 < kChunk)
+    nsteps = 64u * kParts;
+#pragma unroll
+    for (int p = kParts - 1; p >= 0; --p) if (fm[p] != ~0ull) nsteps = 64u * p + (uint32_t)__builtin_ctzll(~fm[p]);
+    // wave-uniform values are read with readlane / readfirstlane so that they, and the addresses derived from them, live in
+    // scalar registers: the vector register file is the scarce resource of this kernel
+    auto row_value = [&](const uint32_t (&v)[kParts], uint32_t k) -> uint32_t {      // v of row k (k wave-uniform)
+        uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v[0], (int)(k & 63u));
+#pragma unroll
+        for (int p = 1; p < kParts; ++p) if ((k >> 6) == (uint32_t)p) r = (uint32_t)__builtin_amdgcn_readlane((int)v[p], (int)(k & 63u));
+        return r;
+    };
+    nlist = row_value(inc, nsteps - 1u);
+    // ---- chunk set-up 3: fill the work list from the kept ballots ----
+    for (uint32_t k = wave; k < nsteps; k += kWaves) {
+        const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.allrows[cursor + k]);
+        uint32_t pos = row_value(inc, k) - row_value(c, k);
+        uint32_t cnt = 0;
+        const uint32_t words = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.words[k]);
+        for (uint32_t g = words & 0xFFu; g < (words >> 8); ++g) {
+            const unsigned long long m = L.hit[k][g];
+            if ((m >> lane) & 1ull) L.list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
+            const uint32_t c = (uint32_t)__popcll(m);
+            pos += c; cnt += c;
+        }
+        if (lane == 0) L.pending[k] = cnt;
+    }
+}
+
+// Every block of the chunk is done: exact masks for the next chunk; returns the number of final pixels.  One workgroup barrier inside.
+template <bool GROUPS>
+__device__ __forceinline__ uint32_t publish_chunk_masks(const Lds &L, uint32_t nsteps, uint32_t lane, uint32_t wave)
+{
+    // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
+    {
+        constexpr int kRowsPerWave = kTileH / kWaves;
+        // once per chunk: hide `lane` from the optimiser here, or it computes this unrolled loop's LDS addresses at kernel
+        // entry and keeps them in (in fact: spills them from) vector registers for the whole kernel
+        uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
+        const uint32_t nfinal = rescan_final(L.vis, L.colfin, L.rowfin, lane_here, L.firstid[nsteps - 1], (int32_t)wave * kRowsPerWave,
+                                             (int32_t)(wave + 1) * kRowsPerWave);
+        if (lane == 0) L.part[wave] = nfinal;
+    }
+    __syncthreads();
+    if constexpr (GROUPS)
+        if (wave == 0) refresh_fin4(L.colfin, L.rowfin, L.colfin4, L.rowfin4, lane);   // (the other waves may start the next chunk on the old four-line masks: they lag, they do not lie)
+    uint32_t all = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) all += L.part[w];
+    return all;
+}
+
+// The fragment stage on the LDS tile; one wave writes one 256-byte row segment.
+template <bool WRITE_VIS, bool COMPLETE, bool FAST>
+__device__ __forceinline__ void shade_item(const FrameParams &P, const SetupView &V, const ShadeTables &S, const Lds &L, const TileCtx &T, const TilePlace &tp, int32_t tile_x0,
+                                           uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t tid)
+{
+    const int32_t item_w = T.px_hi - T.px_lo + 1;
+    // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
+    if (item_w > 32 || (item_w & (item_w - 1)) != 0) {     // whole tiles, and tiles the target's right edge cuts
+        for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
+            const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
+            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
+            if (px > T.px_hi || py > T.py_hi) continue;
+            const uint32_t id = L.vis[vis_index(lx, ly)];
+            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
+            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            if (WRITE_VIS) vis_out[o] = id;
+        }
+    } else {
+        // a strip (32, 16, 8 or 4 pixels wide): lanes run over the pixels of the strip, not of the 64 x 64 tile -- a 4-pixel strip is
+        // shaded by four waves in one trip, not by four lanes of every wave in four
+        const int32_t w_shift = 31 - __builtin_clz(item_w);
+        for (int k = tid; k < ((T.py_hi - T.py_lo + 1) << w_shift); k += kTileThreads) {
+            const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
+            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
+            const uint32_t id = L.vis[vis_index(lx, ly)];
+            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
+            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
+            if (WRITE_VIS) vis_out[o] = id;
+        }
+    }
+}
+} // namespace tile
+
 // Two variants.  COMPLETE = false is the frame's main launch, one workgroup per planned item: it draws every primitive that
 // needs no clipping and is not oversized -- all of them in ordinary views -- and files an item that met one of the others
 // in `redo`.  COMPLETE = true is a small persistent launch that renders the filed items again, this time with the generic
@@ -1467,61 +1765,50 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
                                                        uint32_t *__restrict__ rgba, uint32_t *__restrict__ vis_out, uint32_t *stats,
                                                        uint32_t *__restrict__ last_blocks, uint32_t *__restrict__ redo)
 {
+    using namespace tile;
     uint32_t *const redo_count = work_count + 3;           // items handed to the complete variant
-    constexpr int kWaves = kTileThreads / 64;
-    constexpr int kNV = kBlockVerts * kBlockVerts;         // 81
-    constexpr uint32_t kChunk = 4096;                      // work-list entries per chunk (>= one full block row: nb <= 1024)
-    constexpr int kMaxSteps = 128;                // block rows per chunk
-    constexpr int kHitWords = 16;                          // 64-bit ballots per block row (nb <= 1024)
-    constexpr int kRescanEvery = 1;          // publish new masks when the frontier moved this many steps
+    // ---- LDS (64 KB): separate arrays, bundled into `L` for the phases (tile::Lds) ----
     __shared__ uint32_t s_vis[kTileW * kTileH];
-    // The waves' private arrays of the block loop share their LDS with the ballots of the list building (s_hit): the ballots are dead
-    // from the barrier behind the list fill to the barrier behind the block loop, the private arrays live only between the two.  The
-    // kernel's LDS falls from 80.5 to 64 KB: two of its workgroups (this frame's last, the next frame's first) then leave a CU 32 KB for
-    // the set-up pass that runs beside them, where they left 2.8 -- C4 -1.4 %, top-down camera -0.9 % (round 5; spent on chunks of 192
-    // block rows instead, the 16 KB lose: 0.7189 -> 0.7239 ms).
-    constexpr int kBlockPrims = 2 * kBlockCells * kBlockCells;
-    struct WaveLds {
-        int2 xy[kWaves][kNV];                              // per wave: snapped vertices of the current block (from k_block_setup)
-        uint8_t alive[kWaves][kBlockPrims];                // per wave: the block's alive primitives (cell << 1 | odd), compacted
-        uint8_t surv[kWaves][kBlockPrims];                 // per wave: those of them that survive against this tile
-        uint8_t lines[kWaves][kBlockPrims];                // per wave: ... and how many lines each of them has inside the tile
-    };
-    constexpr size_t kHitBytes = sizeof(unsigned long long) * kMaxSteps * kHitWords;
-    __shared__ __attribute__((aligned(16))) unsigned char s_overlay[sizeof(WaveLds) > kHitBytes ? sizeof(WaveLds) : kHitBytes];
-    unsigned long long (&s_hit)[kMaxSteps][kHitWords] = *reinterpret_cast<unsigned long long (*)[kMaxSteps][kHitWords]>(s_overlay);   // 64-bit ballots per block row (nb <= 1024)
+    __shared__ __attribute__((aligned(16))) unsigned char s_overlay[kOverlayBytes];   // list-building ballots, then the waves' private arrays (WaveLds)
+    __shared__ uint32_t s_list[kChunk];
+    __shared__ uint32_t s_cnt[kMaxSteps];
+    __shared__ uint16_t s_words[kMaxSteps];
+    __shared__ uint32_t s_pending[kMaxSteps];
+    __shared__ uint32_t s_firstid[kMaxSteps];
+    __shared__ uint16_t s_allrows[1024];
+    __shared__ uint32_t s_rc[1024];
+    __shared__ uint32_t s_colfin[kTileW * 2];
+    __shared__ uint32_t s_rowfin[kTileH * 2];
+    __shared__ uint32_t s_colfin4[kTileW / 4 * 2], s_rowfin4[kTileH / 4 * 2];
+    __shared__ uint32_t s_part[kWaves];
+    __shared__ unsigned long long s_rows[16];
+    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
+    __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
+    __shared__ float s_thr[256];
+    __shared__ uint32_t s_per[65];
     WaveLds &s_wave = *reinterpret_cast<WaveLds *>(s_overlay);
     int2 (&sXY)[kWaves][kNV] = s_wave.xy;
     uint8_t (&sC)[kWaves][kBlockPrims] = s_wave.alive;
     uint8_t (&sS)[kWaves][kBlockPrims] = s_wave.surv;
-    constexpr uint32_t kWideLines = 28, kBalGain = 2;      // lane dealing by line counts: looked at when a survivor has more lines than this / taken when it saves this many trips
     uint8_t (&sL)[kWaves][kBlockPrims] = s_wave.lines;
-    __shared__ uint32_t s_list[kChunk];                    // bx | by << 10 | step << 20
-    __shared__ uint32_t s_cnt[kMaxSteps];                  // candidates per step
-    __shared__ uint16_t s_words[kMaxSteps];                // per step: first | end << 8 of the 64-block groups its ballots were taken for
-    __shared__ uint32_t s_pending[kMaxSteps];              // blocks of the step not finished yet
-    __shared__ uint32_t s_firstid[kMaxSteps];
-    __shared__ uint16_t s_allrows[1024];                   // block rows that reach the tile, descending (nb <= 1024)
-    __shared__ uint32_t s_rc[1024];                        // per block row: first | end << 16 of the blocks that can reach this tile column (kept from the row mask pass)
-    __shared__ uint32_t s_colfin[kTileW * 2];
-    __shared__ uint32_t s_rowfin[kTileH * 2];
-    __shared__ uint32_t s_colfin4[kTileW / 4 * 2], s_rowfin4[kTileH / 4 * 2];   // four-line masks (refresh_fin4)
-    __shared__ uint32_t s_part[kWaves];
-    __shared__ unsigned long long s_rows[16];              // bit r of word w: block row 64w + r still to do for this tile
-    __shared__ uint32_t s_next, s_lock, s_done, s_frontier, s_published, s_blocks, s_redo, s_item;
-    __shared__ __attribute__((aligned(16))) float s_lut[kLutFloats];
-    __shared__ float s_thr[256];
-    __shared__ uint32_t s_per[65];                         // [survivors]: lanes per survivor | ceil(2^16 / that) << 7 | survivors per round << 24
+    Lds L;
+    L.vis = s_vis; L.hit = reinterpret_cast<unsigned long long (*)[kHitWords]>(s_overlay);
+    L.xy = s_wave.xy; L.alive = s_wave.alive; L.surv = s_wave.surv; L.lines = s_wave.lines;
+    L.list = s_list; L.cnt = s_cnt; L.words = s_words; L.pending = s_pending; L.firstid = s_firstid; L.allrows = s_allrows; L.rc = s_rc;
+    L.colfin = s_colfin; L.rowfin = s_rowfin; L.colfin4 = s_colfin4; L.rowfin4 = s_rowfin4; L.part = s_part; L.rows = s_rows;
+    L.next = &s_next; L.lock = &s_lock; L.done = &s_done; L.frontier = &s_frontier; L.published = &s_published; L.blocks = &s_blocks; L.redo = &s_redo;
+    L.per = s_per;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform: keep it (and what derives from it) scalar
     VF_PH_INIT
-    VF_RC(RasterCounts RC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_nsurv = 0, rc_iters = 0, rc_live = 0, rc_empty = 0, rc_alive = 0, rc_apass = 0, rc_act = 0;)
+    VF_RC(RasterCounts RC = {};)
     uint32_t redo_at = blockIdx.x;                         // COMPLETE: position in the list of items to render again
     if (COMPLETE && redo_at >= *redo_count) return;        // (normally the case for every workgroup of that launch)
     for (int k = tid; k < kLutFloats; k += kTileThreads) s_lut[k] = lut_linear[k];
     for (int k = tid; k < 256; k += kTileThreads) s_thr[k] = thresh[k];
     if (tid <= 64u) { const uint32_t per = tid ? 64u / tid : 64u; s_per[tid] = per | (((65536u + per - 1u) / per) << 7) | ((64u / per) << 24); }
+    const ShadeTables S = { s_lut, s_thr };
     const uint32_t nwork = *work_count;
     uint32_t pulled = 0;
     if (!COMPLETE) {
@@ -1530,7 +1817,7 @@ __global__ __launch_bounds__(kTileThreads, VF_TILE_MIN_WAVES) void k_tile(FrameP
         pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
         if (pulled >= nwork) return;
     }
-next_item:
+    for (;;) {                                             // ---- the item loop: a persistent workgroup draws items until the queue is empty ----
     VF_PH(12)                                              // hand-over: wait for the other waves, pull the next item
     const uint32_t item_idx = COMPLETE ? redo[redo_at] : pulled;
     const uint64_t t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock: scheduling feedback + diagnostics
@@ -1544,7 +1831,6 @@ next_item:
     const int32_t tile_x0 = T.px_lo;                       // the tile's left edge (T.px_lo becomes the strip's below)
     work_strip(item, T.px_lo, T.px_hi);                    // heavy tiles arrive as 2..16 column strips
     const uint32_t tile_pixels = (uint32_t)(T.px_hi - T.px_lo + 1) * (uint32_t)(T.py_hi - T.py_lo + 1);
-
     const uint64_t row_full = ~0ull >> (63 - (T.px_hi - T.px_lo));   // row mask of a fully final row of this tile / strip
 
     for (int k = tid; k < kTileW * kTileH; k += kTileThreads) s_vis[k] = 0u;
@@ -1555,189 +1841,25 @@ next_item:
     if (tid == 0) { s_done = 0; s_blocks = 0; s_redo = 0; }
     __syncthreads();
     VF_PH(13)                                              // item record, tile state
-    // ---- block rows whose box touches the tile (most tiles of a frame see none: background) ----
-    for (uint32_t base = 0; base < P.nb; base += kTileThreads) {
-        const uint32_t r = base + tid;
-        bool hit = false;
-        if (r < P.nb) {
-            const PixelBox rr = row_boxes[r];
-            const uint32_t lo = rc_lo[tcol * P.nb + r], hi = rc_hi[tcol * P.nb + r];
-            s_rc[r] = lo < hi ? lo | (hi << 16) : 1u;                  // (1 = the empty range [1, 0))
-            hit = lo < hi && rr.x0 <= rr.x1 && rr.x1 >= T.px_lo && rr.x0 <= T.px_hi && rr.y1 >= T.py_lo && rr.y0 <= T.py_hi;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0 && m) s_rows[r >> 6] = m;            // r is a multiple of 64 for lane 0
-    }
-    __syncthreads();
-    VF_PH(14)                                              // row mask
-
-    // ---- the hit rows as a list, highest first (= descending primitive id): wave w expands words 15 - w, 15 - w - kWaves, ... ----
-    uint32_t nrows_total = 0;
-    {
-        uint32_t cnt[16];
-#pragma unroll
-        for (uint32_t w = 0; w < 16u; ++w) { cnt[w] = (uint32_t)__popcll(s_rows[w]); nrows_total += cnt[w]; }
-        for (uint32_t word = 15u - wave; word < 16u; word -= (uint32_t)kWaves) {     // (unsigned wrap ends the loop)
-            uint32_t above = 0;                            // hit rows in the words above this one
-#pragma unroll
-            for (uint32_t w = 0; w < 16u; ++w) above += w > word ? cnt[w] : 0u;
-            const unsigned long long m = s_rows[word];
-            const uint32_t b = 63u - lane;                 // lane 0 takes the highest row of the word
-            if ((m >> b) & 1ull) s_allrows[above + (uint32_t)__popcll(b == 63u ? 0ull : m >> (b + 1u))] = (uint16_t)(word * 64u + b);
-        }
-    }
-    __syncthreads();
-
+    const uint32_t nrows_total = list_block_rows(P, L, T, row_boxes, rc_lo, rc_hi, tcol, tid, lane, wave VF_PH_PASS);
     VF_PH(8)                                                // item start, tile state, row list
     uint32_t dbg_loop = 0;                                 // (VF_DIAG_ITEM=1 only; dead code otherwise)
     const uint32_t hit_words = (P.nb + 63u) / 64u;
-    // (the frontier words are read while other waves write them: relaxed atomic loads on the LDS variables themselves -- a `volatile`
-    //  pointer loses the address space, the loads become FLAT ones and their 64-bit generic addresses live in (spilled) vector registers)
-    auto lds_peek = [](const uint32_t *p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-
-    // a depth slice draws its part of the row list (the complete variant redraws the whole strip, whichever slice filed it)
-    constexpr uint32_t lg_slices = 0u;
-    uint32_t row_first = 0;
-    for (uint32_t cursor = row_first; cursor < nrows_total;) {     // uniform: nothing (left) to draw for this tile ends the loop
-        // ---- chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile;
-        //      the ballots are kept for the fill pass ----
+    for (uint32_t cursor = 0; cursor < nrows_total;) {     // ---- chunks of <= kMaxSteps block rows, nearest first; uniform: nothing (left) to draw ends the loop ----
+        // chunk set-up 1: each wave tests the blocks of its rows (the next <= kMaxSteps of the list) against the tile; the ballots are kept
         const uint32_t nrowsteps = min((uint32_t)kMaxSteps, nrows_total - cursor);
         if (tid == 0) { s_next = 0; s_lock = 0; s_frontier = 0; s_published = 0; }
-        // (in the kernel instantiation WITHOUT line groups only -- the one a handle ends up with when its items are narrow strips of
-        //  far-field tiles, hundreds of rows each: C4, a rank of eight 0.214 -> 0.199 ms; the other instantiation's wide items have a
-        //  dozen rows and lose 1 % to the longer code: measured both ways, EXPERIMENTS.md)
-        if (!GROUPS) {
-        // Lanes = (row, block) pairs: a row's range holds a dozen blocks in the far field and fewer elsewhere, so a wave takes EIGHT of
-        // the chunk's rows at once, eight lanes each (round 4; before: four rows per pass, 64 lanes per row, ten of them busy -- two
-        // passes, i.e. two memory round trips, and four times the instructions per chunk).  Two blocks per lane and trip are requested
-        // together: the latency of the bounds -- the whole cost of this phase -- is paid once per sixteen blocks of a row.  Hits are
-        // OR-ed into the row's ballot words (the list fill reads the same words as before: same list, same order).
-        {
-            const uint32_t rsub = lane >> 3, bsub = lane & 7u;
-            uint32_t *const hit32 = reinterpret_cast<uint32_t *>(&s_hit[0][0]);
-            for (uint32_t kbase = 0; kbase < nrowsteps; kbase += 8u * kWaves) {            // (one trip for a chunk of <= 128 rows)
-                const uint32_t k = kbase + wave + rsub * kWaves;
-                const bool valid = k < nrowsteps;
-                uint32_t by = 0, lo = 1, hi = 0;
-                if (valid) { by = s_allrows[cursor + k]; const uint32_t range = s_rc[by]; lo = range & 0xFFFFu; hi = range >> 16; }
-                const uint32_t g_first = lo >> 6, g_last = lo < hi ? ((hi - 1u) >> 6) + 1u : g_first;
-                if (valid && bsub == 0u) for (uint32_t g = g_first; g < g_last; ++g) s_hit[k][g] = 0ull;
-                __builtin_amdgcn_wave_barrier();            // (LDS operations of one wave complete in order: the zeros are behind us)
-                uint32_t cnt = 0;
-                for (uint32_t b0 = lo + bsub; b0 < hi; b0 += 16u) {
-                    const uint32_t b1 = b0 + 8u;
-                    const bool in1 = b1 < hi;
-                    const uint32_t i0 = by * P.nb + b0, i1 = by * P.nb + (in1 ? b1 : b0);
-                    const PixelBox box0 = V.recs[i0].box, box1 = V.recs[i1].box;
-                    const float4 seg0 = cap_seg[i0], seg1 = cap_seg[i1];
-                    const float rad0 = cap_rad[i0], rad1 = cap_rad[i1];
-                    if (block_is_candidate<GROUPS>(box0, seg0, rad0, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b0 >> 5)], 1u << (b0 & 31u)); ++cnt; }
-                    if (in1 && block_is_candidate<GROUPS>(box1, seg1, rad1, T)) { atomicOr(&hit32[k * (2u * kHitWords) + (b1 >> 5)], 1u << (b1 & 31u)); ++cnt; }
-                }
-                // the row's eight lanes: quad, the other quad (DPP, no LDS round trips)
-                cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-                cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-                cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror
-                // (the list fill reads the ballots of groups g_first .. g_last - 1 only: the others are never written)
-                if (valid && bsub == 0u) { s_cnt[k] = cnt; s_words[k] = (uint16_t)(g_first < g_last ? g_first | (g_last << 8) : 0u); s_firstid[k] = 2u * (by * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
-            }
-        }
-        } else {
-        // Four rows per pass: their bounds (pixel box, capsule) are fetched together, so the global-memory latency -- the
-        // whole cost of this phase -- is paid once per pass instead of once per row and array.
-        constexpr int kRowsAtOnce = 4;
-        for (uint32_t k0 = wave; k0 < nrowsteps; k0 += kRowsAtOnce * kWaves) {
-            uint32_t by[kRowsAtOnce], bx_lo[kRowsAtOnce], bx_hi[kRowsAtOnce], cnt[kRowsAtOnce];
-#pragma unroll
-            for (int r = 0; r < kRowsAtOnce; ++r) {
-                const uint32_t k = k0 + (uint32_t)r * kWaves;
-                const bool valid = k < nrowsteps;
-                by[r] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]) : 0u;
-                // only blocks [bx_lo, bx_hi) of the row can reach the tile column; an absent row gets an empty range
-                const uint32_t range = valid ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rc[by[r]]) : 1u;
-                bx_lo[r] = range & 0xFFFFu;
-                bx_hi[r] = range >> 16;
-                cnt[r] = 0u;
-            }
-            uint32_t g_first = hit_words, g_last = 0;                 // groups of 64 blocks that hold any block of the four ranges
-#pragma unroll
-            for (int r = 0; r < kRowsAtOnce; ++r)
-                if (bx_lo[r] < bx_hi[r]) { g_first = min(g_first, bx_lo[r] >> 6); g_last = max(g_last, ((bx_hi[r] - 1u) >> 6) + 1u); }
-            for (uint32_t g = g_first; g < g_last; ++g) {
-                const uint32_t bx = g * 64u + lane;
-                PixelBox box[kRowsAtOnce];
-                float4 seg[kRowsAtOnce];
-                float rad[kRowsAtOnce];
-                bool in[kRowsAtOnce];
-#pragma unroll
-                for (int r = 0; r < kRowsAtOnce; ++r) {
-                    in[r] = bx >= bx_lo[r] && bx < bx_hi[r];
-                    box[r] = PixelBox{ 1, 1, 0, 0 }; seg[r] = make_float4(0.f, 0.f, 0.f, 0.f); rad[r] = 0.0f;
-                    if (in[r]) {
-                        const uint32_t bidx = by[r] * P.nb + bx;
-                        box[r] = V.recs[bidx].box; seg[r] = cap_seg[bidx]; rad[r] = cap_rad[bidx];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < kRowsAtOnce; ++r) {
-                    const uint32_t k = k0 + (uint32_t)r * kWaves;
-                    if (k >= nrowsteps) continue;                                   // uniform
-                    const unsigned long long m = __ballot(in[r] && block_is_candidate<GROUPS>(box[r], seg[r], rad[r], T));
-                    if (lane == 0) s_hit[k][g] = m;
-                    cnt[r] += (uint32_t)__popcll(m);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < kRowsAtOnce; ++r) {
-                const uint32_t k = k0 + (uint32_t)r * kWaves;
-                // (the list fill reads the ballots of groups g_first .. g_last - 1 only: the others are never written)
-                if (lane == 0 && k < nrowsteps) { s_cnt[k] = cnt[r]; s_words[k] = (uint16_t)(g_first < g_last ? g_first | (g_last << 8) : 0u); s_firstid[k] = 2u * (by[r] * kBlockCells * P.nm1) + 1u; }   // smallest (id + 1) of the row
-            }
-        }
-        }
+        // (lanes = (row, block) pairs in the kernel instantiation WITHOUT line groups only -- the one a handle ends up with when its items
+        //  are narrow strips of far-field tiles, hundreds of rows each: C4, a rank of eight 0.214 -> 0.199 ms; the other instantiation's
+        //  wide items have a dozen rows and lose 1 % to the longer code: measured both ways, EXPERIMENTS.md)
+        if (!GROUPS) test_candidates_pairs<GROUPS>(P, V, L, T, cap_seg, cap_rad, cursor, nrowsteps, lane, wave);
+        else test_candidates_rows<GROUPS>(P, V, L, T, cap_seg, cap_rad, cursor, nrowsteps, hit_words, lane, wave);
         VF_PH(9)                                            // candidate tests
         __syncthreads();
         VF_PH(10)                                           // ... waiting for the slowest wave
-        // ---- chunk set-up 2: every wave scans the row counts for itself (64 rows at a time, DPP), so all agree on the list offsets
-        //      and on how many rows fit the list without another barrier; rows that do not fit wait for the next chunk ----
-        constexpr int kParts = kMaxSteps / 64;              // the rows of a chunk, 64 (one per lane) at a time
-        static_assert(kMaxSteps % 64 == 0 && kParts >= 1 && kParts <= 4, "the offset scan below works on 64-row parts");
-        uint32_t c[kParts], inc[kParts];
-        unsigned long long fm[kParts];
-#pragma unroll
-        for (int p = 0; p < kParts; ++p) {
-            c[p] = lane + 64u * p < nrowsteps ? s_cnt[lane + 64u * p] : 0u;
-            inc[p] = wave_scan_add(c[p]);
-            if (p) inc[p] += (uint32_t)__builtin_amdgcn_readlane((int)inc[p - 1], 63);
-            fm[p] = __ballot(lane + 64u * p < nrowsteps && inc[p] <= kChunk);
-        }
-        // rows are admitted in order: stop at the first one that does not fit (a single row always fits: nb <= 1024 < kChunk)
-        uint32_t nsteps = 64u * kParts;
-#pragma unroll
-        for (int p = kParts - 1; p >= 0; --p) if (fm[p] != ~0ull) nsteps = 64u * p + (uint32_t)__builtin_ctzll(~fm[p]);
-        // wave-uniform values are read with readlane / readfirstlane so that they, and the addresses derived from them, live in
-        // scalar registers: the vector register file is the scarce resource of this kernel
-        auto row_value = [&](const uint32_t (&v)[kParts], uint32_t k) -> uint32_t {      // v of row k (k wave-uniform)
-            uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v[0], (int)(k & 63u));
-#pragma unroll
-            for (int p = 1; p < kParts; ++p) if ((k >> 6) == (uint32_t)p) r = (uint32_t)__builtin_amdgcn_readlane((int)v[p], (int)(k & 63u));
-            return r;
-        };
-        const uint32_t nlist = row_value(inc, nsteps - 1u);
-        // ---- chunk set-up 3: fill the work list from the kept ballots ----
-        for (uint32_t k = wave; k < nsteps; k += kWaves) {
-            const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_allrows[cursor + k]);
-            uint32_t pos = row_value(inc, k) - row_value(c, k);
-            uint32_t cnt = 0;
-            const uint32_t words = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_words[k]);
-            for (uint32_t g = words & 0xFFu; g < (words >> 8); ++g) {
-                const unsigned long long m = s_hit[k][g];
-                if ((m >> lane) & 1ull) s_list[pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g * 64u + lane) | (by << 10) | (k << 20);
-                const uint32_t c = (uint32_t)__popcll(m);
-                pos += c; cnt += c;
-            }
-            if (lane == 0) s_pending[k] = cnt;
-        }
+        // chunk set-up 2 + 3: list offsets, the work list
+        uint32_t nsteps, nlist;
+        fill_work_list(L, cursor, nrowsteps, lane, wave, nsteps, nlist);
         cursor += nsteps;
         VF_PH(11)                                           // scan + list fill
         __syncthreads();
@@ -1868,7 +1990,7 @@ next_item:
                     nsurv += (uint32_t)__popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
-                VF_RC(if (lane == 0) { rc_nsurv += nsurv; rc_live++; rc_empty += nsurv ? 0u : 1u; rc_alive += n_alive; rc_apass += (n_alive + 63u) / 64u; })
+                VF_RC(if (lane == 0) { RC.nsurv += nsurv; RC.live++; RC.empty += nsurv ? 0u : 1u; RC.alive += n_alive; RC.apass += (n_alive + 63u) / 64u; })
                 VF_PH(3)
                 // ---- pass B: the survivors share the wave: with few of them, 2..64 lanes split the lines of one triangle ----
                 {
@@ -1915,7 +2037,7 @@ next_item:
                     for (uint32_t sbase = 0; sbase < nsurv; sbase += group) {      // (balanced: one round)
                         const uint32_t sidx = sbase + q;
                         const bool act = balanced ? lane < b_used : (q < group && sidx < nsurv);
-                        VF_RC({ const uint32_t na = (uint32_t)__popcll(__ballot(act)); if (lane == 0) { rc_iters++; rc_act += na; } })
+                        VF_RC({ const uint32_t na = (uint32_t)__popcll(__ballot(act)); if (lane == 0) { RC.iters++; RC.act += na; } })
                         if (act) {
                             const uint32_t code = balanced ? (b_mine & 0xFFu) : (uint32_t)sS[wave][sidx];
                             const uint32_t my_sub = balanced ? lane - ((b_mine >> 8) & 0xFFu) : sub, my_n = balanced ? b_mine >> 16 : per;
@@ -1967,23 +2089,7 @@ next_item:
         __syncthreads();
         if (kDiagItem == 1) dbg_loop += (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
         if (s_done) break;                                             // uniform
-        // ---- end of chunk: every block of the chunk is done; publish exact masks for the next chunk ----
-        {
-            constexpr int kRowsPerWave = kTileH / kWaves;
-            // once per chunk: hide `lane` from the optimiser here, or it computes this unrolled loop's LDS addresses at kernel
-            // entry and keeps them in (in fact: spills them from) vector registers for the whole kernel
-            uint32_t lane_here = lane;
-            asm volatile("" : "+v"(lane_here));
-            const uint32_t nfinal = rescan_final(s_vis, s_colfin, s_rowfin, lane_here, s_firstid[nsteps - 1], (int32_t)wave * kRowsPerWave,
-                                                 (int32_t)(wave + 1) * kRowsPerWave);
-            if (lane == 0) s_part[wave] = nfinal;
-        }
-        __syncthreads();
-        if constexpr (GROUPS)
-            if (wave == 0) refresh_fin4(s_colfin, s_rowfin, s_colfin4, s_rowfin4, lane);   // (the other waves may start the next chunk on the old four-line masks: they lag, they do not lie)
-        uint32_t all = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) all += s_part[w];
+        const uint32_t all = publish_chunk_masks<GROUPS>(L, nsteps, lane, wave);
         VF_PH(6)
         if (all >= tile_pixels) break;                                 // uniform: the whole tile is final
     }
@@ -1997,68 +2103,39 @@ next_item:
         stats[5 + 4 * item_idx] = kDiagItem == 1 ? dbg_loop : kDiagItem == 2 ? work[item_idx].y : kDiagItem == 3 ? (uint32_t)t_start : s_blocks;
         stats[6 + 4 * item_idx] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);       // raster phase, 10 ns ticks
     }
-
-    const int32_t item_w = T.px_hi - T.px_lo + 1;
-    constexpr bool shade = true;
-    // ---- fragment stage on the LDS tile; one wave writes one 256-byte row segment ----
-    ShadeTables S = { s_lut, s_thr };
-    if (shade) {
-    if (item_w > 32 || (item_w & (item_w - 1)) != 0) {     // whole tiles, and tiles the target's right edge cuts
-        for (int k = tid; k < kTileW * kTileH; k += kTileThreads) {
-            const int32_t lx = k & (kTileW - 1), ly = k / kTileW;
-            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
-            if (px > T.px_hi || py > T.py_hi) continue;
-            const uint32_t id = s_vis[vis_index(lx, ly)];
-            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
-            if (WRITE_VIS) vis_out[o] = id;
-        }
-    } else {
-        // a strip (32, 16, 8 or 4 pixels wide): lanes run over the pixels of the strip, not of the 64 x 64 tile -- a 4-pixel strip is
-        // shaded by four waves in one trip, not by four lanes of every wave in four
-        const int32_t w_shift = 31 - __builtin_clz(item_w);
-        for (int k = tid; k < ((T.py_hi - T.py_lo + 1) << w_shift); k += kTileThreads) {
-            const int32_t ly = k >> w_shift, lx = k - (ly << w_shift);
-            const int32_t px = T.px_lo + lx, py = T.py_lo + ly;
-            const uint32_t id = s_vis[vis_index(lx, ly)];
-            const size_t o = tp.out_base + (size_t)ly * tp.out_stride + (uint32_t)(px - tile_x0);
-            rgba[o] = id ? shade_pixel<COMPLETE, FAST>(P, V, S, id - 1u, px, py) : P.clear_rgba;
-            if (WRITE_VIS) vis_out[o] = id;
-        }
-    }
-    }
+    shade_item<WRITE_VIS, COMPLETE, FAST>(P, V, S, L, T, tp, tile_x0, rgba, vis_out, tid);
     VF_PH(7)
     if (tid == 0) {
         const uint32_t ticks = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
         atomicAdd(&last_blocks[tile], max(ticks, 1u));        // feedback for the next frame's plan: time this tile cost (10 ns ticks)
         if (!COMPLETE)                                        // ... and this piece of it (behind the tile times and the quantum word)
-            last_blocks[(size_t)P.ntx * P.nty + 1u + (size_t)tile * 64u + (work_part(item) << lg_slices) + work_slice(item)] = max(ticks, 1u);
+            last_blocks[(size_t)P.ntx * P.nty + 1u + (size_t)tile * 64u + work_part(item)] = max(ticks, 1u);
         if (stats) stats[7 + 4 * item_idx] = ticks;        // raster + fragment phase
         if (!COMPLETE && s_redo) redo[atomicAdd(redo_count, 1u)] = item_idx;   // this item met a primitive the fast path skips
     }
+    __syncthreads();                                       // the next item re-initialises the tile state
     if constexpr (COMPLETE) {
         redo_at += gridDim.x;
-        __syncthreads();                                   // the next item re-initialises the tile state
-        if (redo_at < *redo_count) goto next_item;
+        if (redo_at >= *redo_count) break;
     }
     else {
-        __syncthreads();
         if (tid == 0) s_item = atomicAdd(work_count + 2, 1u);
         __syncthreads();
         pulled = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
-        if (pulled < nwork) goto next_item;
+        if (pulled >= nwork) break;
+    }
     }
 #ifdef VF_PHASE_PROF   // one flush per workgroup, after its last item (per-item flushes would perturb the hand-over they measure)
     if (stats) {
         unsigned long long *ph = reinterpret_cast<unsigned long long *>(stats + 4 + 4 * ((size_t)P.ntx * P.nty + kSplitBudget));
         if (lane == 0) {
-            for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)ph_acc[p]);
-            for (int p = 8; p < 16; ++p) atomicAdd(&ph[8 + p], (unsigned long long)ph_acc[p]);
-            atomicAdd(&ph[30], (unsigned long long)ph_acc[16]); atomicAdd(&ph[31], (unsigned long long)ph_acc[17]);
-            atomicAdd(&ph[32], (unsigned long long)ph_acc[18]); atomicAdd(&ph[33], (unsigned long long)ph_acc[19]);
-            atomicAdd(&ph[8], (unsigned long long)rc_nsurv); atomicAdd(&ph[9], (unsigned long long)rc_iters);
-            atomicAdd(&ph[10], (unsigned long long)rc_empty); atomicAdd(&ph[15], (unsigned long long)rc_live);
-            atomicAdd(&ph[35], (unsigned long long)rc_alive); atomicAdd(&ph[36], (unsigned long long)rc_apass); atomicAdd(&ph[37], (unsigned long long)rc_act);
+            for (int p = 0; p < 8; ++p) atomicAdd(&ph[p], (unsigned long long)PH.acc[p]);
+            for (int p = 8; p < 16; ++p) atomicAdd(&ph[8 + p], (unsigned long long)PH.acc[p]);
+            atomicAdd(&ph[30], (unsigned long long)PH.acc[16]); atomicAdd(&ph[31], (unsigned long long)PH.acc[17]);
+            atomicAdd(&ph[32], (unsigned long long)PH.acc[18]); atomicAdd(&ph[33], (unsigned long long)PH.acc[19]);
+            atomicAdd(&ph[8], (unsigned long long)RC.nsurv); atomicAdd(&ph[9], (unsigned long long)RC.iters);
+            atomicAdd(&ph[10], (unsigned long long)RC.empty); atomicAdd(&ph[15], (unsigned long long)RC.live);
+            atomicAdd(&ph[35], (unsigned long long)RC.alive); atomicAdd(&ph[36], (unsigned long long)RC.apass); atomicAdd(&ph[37], (unsigned long long)RC.act);
         }
         {   // lanes in the line loop's first step (group tests with line groups, line trips without)
             uint32_t li = RC.l_iter;
