@@ -188,8 +188,12 @@ int vf_terrain_rgba_device(const vf_terrain *t, void **dev_rgba);
  * linear (0.02,0.02,0.03,1), one indexed draw of 6(n-1)^2 indices, vs_main / raster / fs_main
  * (src/shaders/terrain.wgsl:44-91), sRGB store.  Leaves tightly packed RGBA8 (local rows) in HBM.
  * Asynchronous on `stream` (NULL = the context's stream): the output is complete when work queued on `stream` after this
- * call runs.  Planning kernels run on a stream owned by the handle and may overlap the previous frame; how the frame's work
- * is ordered and split follows the times measured on this handle's earlier frames -- that steers speed only, never a pixel.
+ * call runs.  How the frame's work is ordered and split follows the times measured on this handle's earlier frames -- that
+ * steers speed only, never a pixel.  Where the planning kernels run (round 6): for a caller that WAITS for every frame, on
+ * `stream` itself -- and the plan of its next frame, when the inputs have not changed, behind the copy of its next read-back
+ * (vf_terrain_read_rgba / _read_png_scanlines return when the copy is done, not when that plan is); for a caller that submits
+ * a frame while the previous one is in flight, on two streams of the context (made once per process, 17-20 ms), under the
+ * previous frame's tile kernel.
  */
 int vf_terrain_render(vf_terrain *t, void *stream);
 /* BASELINE.json configs[4] ("batch of 64 camera look-ats over one terrain"): n render passes with n uniform blocks over the handle's
@@ -209,7 +213,8 @@ int vf_terrain_render_batch_host(vf_terrain *t, const float *uniforms, uint32_t 
 int vf_terrain_sync(vf_terrain *t);
 
 /* copy_texture_to_buffer + map + un-pad (src/terrain/mod.rs:439-485): local rows [y0, y0+rows)
- * into dst (rows*W*4 bytes).  Synchronises the last render. */
+ * into dst (rows*W*4 bytes).  Waits for the last render and for the copy (work the library queues behind the copy for the
+ * caller's NEXT frame may still be running when this returns: later calls on the handle are ordered after it). */
 int vf_terrain_read_rgba(vf_terrain *t, uint8_t *dst, uint32_t y0, uint32_t rows);
 /* Page-locked host memory for read-back destinations (new; the reference maps a fresh staging buffer per call,
  * src/terrain/mod.rs:446-451).  vf_terrain_read_rgba into such a buffer is ONE DMA transfer (C4: 64 MiB in 1.2 ms); into ordinary

@@ -55,7 +55,7 @@ timeout -k 10 300 python tools/exp_rank_frames.py 2 8 > "$out/rank_frames.log" 2
 echo "== rank 0's stitch"; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 default > "$out/rank0_stitch.log" 2>&1; timeout -k 10 200 python tools/exp_rank0_stitch.py 8 fill >> "$out/rank0_stitch.log" 2>&1; grep period "$out/rank0_stitch.log" | tail -8
 echo "== first frames"; timeout -k 10 200 python tools/exp_cold.py default > "$out/cold.log" 2>&1; timeout -k 10 200 python tools/exp_cold.py fill >> "$out/cold.log" 2>&1; grep rep "$out/cold.log"
 echo "== one-shot path, cold process"; timeout -k 10 200 python tools/one_shot.py > "$out/one_shot.json" 2> "$out/one_shot.err"; cat "$out/one_shot.json"
-echo "== C5: poses at rest, per-pose times of the orbit, schedules"; (VF_C5_STATIC=1 VF_C5_POSES=1 timeout -k 10 300 python tools/exp_c5.py r05) > "$out/c5_orbit.log" 2>&1; cat "$out/c5_orbit.log"
+echo "== C5: poses at rest, per-pose times of the orbit, schedules"; (VF_C5_STATIC=1 VF_C5_POSES=1 timeout -k 10 300 python tools/exp_c5.py r06) > "$out/c5_orbit.log" 2>&1; cat "$out/c5_orbit.log"
 if [ -f build/variants/libvf_gantt.so ]; then for c in pose8 pose0 orbit7 orbit60; do VF_C5=1 VF_HIP_LIB=$PWD/build/variants/libvf_gantt.so timeout -k 10 200 python tools/exp_gantt.py $c; done > "$out/c5_gantt.log" 2>&1; grep tile_ms "$out/c5_gantt.log"; fi
 echo "== eight virtual ranks"; timeout -k 10 600 python tools/rehearse_virtual.py 8 > "$out/rehearse_8ranks.json" 2> "$out/rehearse_8ranks.err"; echo "rc=$?"; tail -c 300 "$out/rehearse_8ranks.json"
 echo "== rehearsal"; for n in 2 4; do timeout -k 10 600 python bench.py --gpus $n --rehearse --no-cpu-baseline --steps 5 > "$out/rehearse_${n}ranks.json" 2> "$out/rehearse_${n}ranks.err"; echo "rc=$?"; tail -c 300 "$out/rehearse_${n}ranks.json"; done
