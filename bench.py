@@ -617,6 +617,14 @@ def main():
         roofline["valu"] = {"issue_frac": sq["valu_busy_frac"], "lane_efficiency": sq["active_lanes_per_valu_inst"] / 64.0,
                             "lane_throughput_frac": sq["valu_busy_frac"] * sq["active_lanes_per_valu_inst"] / 64.0,
                             "wave_insts_per_frame": sq.get("valu_wave_insts"), "unit": "fraction of peak vector issue"}
+        if sq.get("setup_valu_wave_insts"):
+            # the frame as vector issue time: the tile kernel's and the set-up pass's wave instructions (the pass of the NEXT frame runs in
+            # this frame's idle issue slots), four cycles each on a 16-lane SIMD, over the chip's SIMDs at the clock the device reports
+            di0 = t.device_info()
+            simds, hz = 4 * int(di0["compute_units"]), 1e3 * float(di0["clock_khz"])
+            insts = float(sq["valu_wave_insts"]) + float(sq["setup_valu_wave_insts"])
+            roofline["valu"].update({"setup_pass_wave_insts_per_frame": sq["setup_valu_wave_insts"],
+                                     "frame_vector_issue_ms": insts * 4.0 / (simds * hz) * 1e3, "simds": simds, "clock_ghz": hz / 1e9})
 
     # ---- CPU baseline: the oracle (a port, not the reference: it cannot be built here) on this box's host cores -----
     cpu = None

@@ -85,6 +85,8 @@ def sq_passes(suffix):
                 lines.append(f"  {kern:34s} {ctr:26s} {v:16.0f}   ({LAUNCHES[kern]} launches)")
             if kern == main:
                 sq[ctr] = v
+            if kern == "vf::k_block_setup" and ctr == "SQ_INSTS_VALU":
+                sq["setup_SQ_INSTS_VALU"] = v                # the set-up pass runs in the tile kernel's idle issue slots: its instructions count against the same frame
     return sq, lines
 
 
@@ -93,6 +95,7 @@ def sq_block(sq, what):
         "valu_busy_frac": sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
         "valu_wave_insts": sq["SQ_INSTS_VALU"], "salu_wave_insts": sq["SQ_INSTS_SALU"], "lds_wave_insts": sq["SQ_INSTS_LDS"],
         "active_lanes_per_valu_inst": sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"],
+        "setup_valu_wave_insts": sq.get("setup_SQ_INSTS_VALU"),
         "wave_cycles_active_wait_stall": [sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
                                           sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]],
         "note": f"k_tile fast variant, {what}; busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs) -- the counter ticks in quad-cycles, "
