@@ -419,7 +419,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t.enable_timing(True, stats=False)                          # HIP events around the kernels; the kernels themselves run as untimed
+        # HIP events around the kernels of every FOURTH timed frame (every frame when the run is short): the kernels themselves run as
+        # untimed, but two event records per frame on the draw stream keep each kernel from being launched under the one before it and
+        # cost a C4 frame 2 % (tools/exp_timing_cost.py: 20-frame bursts 0.733 untimed, 0.750 with events on every frame, 0.737 on every fourth)
+        t.enable_timing(True, stats=False, sampled=steps >= 8)
         ex_events.clear()
         collect_ex[0] = ex is not None
         t0 = time.perf_counter()
@@ -458,7 +461,8 @@ def main():
     # per timed frame, this rank's HIP events: frame period (end of the previous frame's tile kernel -> end of this one's;
     # back-to-back frames overlap, so this is what a frame costs) and the kernels on the caller's stream
     frame_ms = {"period": frame_stats(tm["frame_period_ms"][1:]), "tile_kernel": frame_stats(tm["frame_tile_ms"]),
-                "clock": "HIP events on the render stream, one pair per frame (vf_terrain_frame_times)"}
+                "clock": "HIP events on the render stream around the kernels of every fourth timed frame (every frame when steps < 8); periods are per frame, "
+                         "from events four frames apart (vf_terrain_enable_timing(t, 3), vf_terrain_frame_times)"}
     frames = args.steps * (world if c5 else 1)
     value = W * H * frames / dt / 1e6
 

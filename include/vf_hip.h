@@ -237,7 +237,10 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
 
 /* enable: 0 off; 1 device times (HIP events around the frame's kernels) and the per-item statistics behind
  * vf_terrain_debug_item_stats / vf_timings.blocks_* (the tile kernel then writes them: a few atomics per drawn block);
- * 2 device times only -- the kernels run exactly as they do untimed (what bench.py times; blocks_* read 0). */
+ * 2 device times only -- the kernels run exactly as they do untimed (blocks_* read 0);
+ * 3 as 2, for every FOURTH frame only (what bench.py times: the two event records a timed frame puts on the draw stream keep
+ *   the next kernel from being launched under the previous one and cost a C4 frame 2 %, tools/exp_timing_cost.py); the frame
+ *   periods vf_timings.total_ms / vf_terrain_frame_times report are then per frame, from events four frames apart. */
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 /* The same HIP events frame by frame (timing enabled; the frames since vf_terrain_enable_timing, at most the last 64, oldest

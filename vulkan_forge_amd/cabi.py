@@ -362,9 +362,10 @@ class Terrain:
         self._check(self.lib.vf_terrain_read_visibility(self.t, out.ctypes.data))
         return out
 
-    def enable_timing(self, on=True, stats=True):
-        """stats=False: HIP events only, the kernels run exactly as untimed (no per-item statistics; blocks_* read 0)."""
-        self._check(self.lib.vf_terrain_enable_timing(self.t, (1 if stats else 2) if on else 0))
+    def enable_timing(self, on=True, stats=True, sampled=False):
+        """stats=False: HIP events only, the kernels run exactly as untimed (no per-item statistics; blocks_* read 0);
+        sampled=True (with stats=False): events on every fourth frame only."""
+        self._check(self.lib.vf_terrain_enable_timing(self.t, (1 if stats else (3 if sampled else 2)) if on else 0))
 
     def item_stats(self):
         """(items, 4) u32 per work item of the last frame: code (local tile | strip << 20 | log2 strips << 24), candidate

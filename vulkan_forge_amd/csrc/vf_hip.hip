@@ -191,6 +191,7 @@ struct FramePlan {
     FrameParams P;
     uint32_t set = 0, ntiles = 0, ev_slot = 0;
     bool solo = false, motion_starts = false, timed = false;     // timed: the plan's three timing events were recorded, in ring slot ev_slot
+    bool sampled = true;                                         // timing level 3: this frame is one of those that carry events
     uint32_t *rc_lo = nullptr, *rc_hi = nullptr, *seg_count = nullptr;
 };
 
@@ -315,6 +316,7 @@ struct vf_terrain {
     static constexpr int kTimingRing = 64;
     bool timing = false;
     bool stats_on = false;               // per-item statistics as well (vf_terrain_enable_timing(t, 1)); 2 = device times only
+    uint32_t timing_every = 1;           // 3 = device times of every 4th frame only: two event records on the draw stream cost a frame 2 % (tools/exp_timing_cost.py)
     hipEvent_t ev[kTimingRing][5] = {};   // plan start, after block boxes, after plan (side stream); after tile, before clear (caller's stream)
     hipEvent_t entry = nullptr;          // caller's stream at render entry (orders a height-cache rebuild after the caller's work)
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
@@ -1126,7 +1128,8 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = f
     hipStream_t side = solo ? s : t->side, side2 = solo ? s : t->side2;
     // (a plan queued ahead of its call records no timing events: its frame has no place in the ring yet -- the slot belongs to whatever
     //  frame is drawn next -- and vf_terrain_timings would pair them with that frame's draw events; draw_frame records them instead)
-    const bool timed = t->timing && !ahead;
+    K.sampled = t->timing_every <= 1u || t->frame_no % t->timing_every == 0u;
+    const bool timed = t->timing && !ahead && K.sampled;
     K.ev_slot = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
     K.timed = timed;
     hipEvent_t *ev = t->ev[K.ev_slot];
@@ -1201,7 +1204,8 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
     //  events are then recorded here -- valid, if not telling -- so that the frame's entry in the ring is complete)
     const uint32_t slot_now = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
     hipEvent_t *ev = t->ev[slot_now];
-    if (t->timing && (!K.timed || K.ev_slot != slot_now)) for (int k = 0; k < 3; ++k) VF_HIP_TRY(hipEventRecord(ev[k], s));
+    const bool timing_now = t->timing && K.sampled;
+    if (timing_now && (!K.timed || K.ev_slot != slot_now)) for (int k = 0; k < 3; ++k) VF_HIP_TRY(hipEventRecord(ev[k], s));
     (void)solo;
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
     uint32_t *stats = t->timing && t->stats_on ? t->d_stats : nullptr;
@@ -1218,7 +1222,7 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
 #endif
     if (t->last_stream && t->last_stream != s && t->rendered && (!overlap_frames || t->last_out == t->d_rgba || stats || write_vis || !t->last_out))
         VF_HIP_TRY(hipStreamWaitEvent(s, t->ps[t->last_set].drawn, 0));
-    if (t->timing) VF_HIP_TRY(hipEventRecord(ev[4], s));
+    if (timing_now) VF_HIP_TRY(hipEventRecord(ev[4], s));
     // line groups in the raster's line loop (vf_kernels.h, raster_fast): whole frames and shards of few ranks -- wide items, triangles
     // with many lines -- gain from them (C4: one GPU -2 %, top-down camera -7 %); a rank of many mostly draws narrow strips, whose
     // triangles have a handful of lines, and is better off with the leaner kernel (VF_GROUPS=0 / 1 overrides)
@@ -1302,7 +1306,7 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
 #undef VF_TILE_ARGS
     }
     else VF_HIP_TRY(hipMemsetAsync(seg_count, 0, sizeof(uint32_t), s));   // (a shard without tiles: what k_clear does on its way in)
-    if (t->timing) { VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
+    if (timing_now) { VF_HIP_TRY(hipEventRecord(ev[3], s)); t->timed_frames++; }
     VF_HIP_TRY(hipEventRecord(S.drawn, s));
     VF_HIP_TRY(hipGetLastError());
     std::memcpy(S.u_used, t->u, sizeof S.u_used);           // the camera this set's tile times (being measured now) belong to
@@ -1753,8 +1757,10 @@ int vf_terrain_enable_timing(vf_terrain *t, int enable)
         VF_HIP_TRY(hipSetDevice(t->ctx->device));
         for (auto &f : t->ev) for (auto &e : f) VF_HIP_TRY(hipEventCreate(&e));
     }
+    if (enable < 0 || enable > 3) return fail(VF_ERR_INVALID, "enable must be 0 .. 3");
     t->timing = enable != 0;
-    t->stats_on = enable == 1;   // 2: HIP events only -- the tile kernel runs exactly as it does untimed (no per-item statistics)
+    t->stats_on = enable == 1;   // 2, 3: HIP events only -- the tile kernel runs exactly as it does untimed (no per-item statistics)
+    t->timing_every = enable == 3 ? 4u : 1u;
     t->timed_frames = 0;     // (re)start the averaging window
     return VF_OK;
 }
@@ -1783,7 +1789,7 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
         // frames rendered back to back overlap (frame f+1 plans while frame f draws): the frame period is what a frame costs
         float span = 0;
         VF_HIP_TRY(hipEventElapsedTime(&span, t->ev[0][3], t->ev[nf - 1][3]));
-        out->total_ms = span / (float)(nf - 1);
+        out->total_ms = span / (float)((nf - 1) * t->timing_every);
     }
     out->frames = nf;
     out->blocks_rasterised = 0; out->blocks_distinct = 0;
@@ -1816,7 +1822,7 @@ int vf_terrain_frame_times(vf_terrain *t, float *tile_ms, float *period_ms, uint
         if (tile_ms) VF_HIP_TRY(hipEventElapsedTime(&tile_ms[k], e[4], e[3]));
         if (period_ms) {
             period_ms[k] = 0.0f;
-            if (k) VF_HIP_TRY(hipEventElapsedTime(&period_ms[k], t->ev[(first + k - 1u) % ring][3], e[3]));
+            if (k) { VF_HIP_TRY(hipEventElapsedTime(&period_ms[k], t->ev[(first + k - 1u) % ring][3], e[3])); period_ms[k] /= (float)t->timing_every; }
         }
     }
     *count = nf;
