@@ -419,6 +419,19 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # the plan chain's times (side streams): from four frames of their own in front of the timed region -- event records between the plan's
+        # kernels delay the chain, and the timed region carries none
+        plan_tm = None
+        if not c5:
+            t.enable_timing(True, stats=False)
+            for _ in range(4):
+                step()
+            flush()
+            torch.cuda.synchronize()
+            plan_tm = t.timings()
+            t.enable_timing(False)
+            if world > 1:
+                dist.barrier()
         # HIP events around the kernels of every FOURTH timed frame (every frame when the run is short): the kernels themselves run as
         # untimed, but two event records per frame on the draw stream keep each kernel from being launched under the one before it and
         # cost a C4 frame 2 % (tools/exp_timing_cost.py: 20-frame bursts 0.733 untimed, 0.750 with events on every frame, 0.737 on every fourth)
@@ -439,6 +452,8 @@ def main():
         collect_ex[0] = False
         tm = t.timings()
         tm["exchange_ms"] = [a.elapsed_time(b) for a, b in ex_events]
+        if plan_tm is not None and steps >= 8:
+            tm["ranges_ms"], tm["plan_ms"] = plan_tm["ranges_ms"], plan_tm["plan_ms"]
         tm["frame_tile_ms"], tm["frame_period_ms"] = t.frame_times()
         tm["raster_groups"] = t.raster_groups()
         t.enable_timing(False)

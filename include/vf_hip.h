@@ -57,8 +57,9 @@ typedef struct vf_device_info {
  * A frame's plan kernels run on a stream of the handle's own and overlap the previous frame's tile kernel, so the first two
  * figures are elapsed times on that stream (they include waiting for free CUs when frames are rendered back to back). */
 typedef struct vf_timings {
-    float ranges_ms;    /* k_block_boxes (per-block pixel boxes and capsules) up to the launch of k_block_setup (side stream, elapsed) */
-    float plan_ms;      /* k_plan + k_plan_sort: background flags, busy-tile list, heaviest first (side stream, elapsed) */
+    float ranges_ms;    /* k_block_boxes (per-block pixel boxes and capsules) up to the launch of k_block_setup (the plan's stream, elapsed) */
+    float plan_ms;      /* k_plan + k_plan_sort: background flags, busy-tile list, heaviest first (the plan's stream, elapsed); both: the last
+                         * plan of each of the handle's two plan states (round 6: a plan may be queued ahead of its frame's call) */
     float tile_ms;      /* k_clear + k_tile (both variants) on the caller's stream: background clear, LDS raster from the set-up pass's records, fragment stage */
     float total_ms;     /* frame period when >= 2 frames were timed back to back, else plan start -> RGBA8 complete */
     uint32_t blocks_rasterised; /* (tile, block) pairs the tile kernel processed (after early-out); 0 at timing level 2 */
@@ -240,7 +241,8 @@ int vf_terrain_read_visibility(vf_terrain *t, uint32_t *dst);
  * 2 device times only -- the kernels run exactly as they do untimed (blocks_* read 0);
  * 3 as 2, for every FOURTH frame only (what bench.py times: the two event records a timed frame puts on the draw stream keep
  *   the next kernel from being launched under the previous one and cost a C4 frame 2 %, tools/exp_timing_cost.py); the frame
- *   periods vf_timings.total_ms / vf_terrain_frame_times report are then per frame, from events four frames apart. */
+ *   periods vf_timings.total_ms / vf_terrain_frame_times report are then per frame, from events four frames apart; the plan chain
+ *   carries no events at this level (ranges_ms / plan_ms read 0: measure them at level 2). */
 int vf_terrain_enable_timing(vf_terrain *t, int enable);
 int vf_terrain_timings(vf_terrain *t, vf_timings *out);
 /* The same HIP events frame by frame (timing enabled; the frames since vf_terrain_enable_timing, at most the last 64, oldest

@@ -189,8 +189,8 @@ static hipError_t ctx_copy_stream(vf_ctx *c, hipStream_t *copy)
 // What the second half of a frame (draw_frame) needs of the first (plan_frame)
 struct FramePlan {
     FrameParams P;
-    uint32_t set = 0, ntiles = 0, ev_slot = 0;
-    bool solo = false, motion_starts = false, timed = false;     // timed: the plan's three timing events were recorded, in ring slot ev_slot
+    uint32_t set = 0, ntiles = 0;
+    bool solo = false, motion_starts = false;
     bool sampled = true;                                         // timing level 3: this frame is one of those that carry events
     uint32_t *rc_lo = nullptr, *rc_hi = nullptr, *seg_count = nullptr;
 };
@@ -257,6 +257,8 @@ struct vf_terrain {
         uint32_t *feedback = nullptr;    // time (10 ns ticks) per tile, added by this set's tile kernel, read two frames later; [ntiles] = split quantum;
                                          // then 64 words per tile: the time of each of its pieces (strip x slice)
         hipEvent_t planned = nullptr, drawn = nullptr, boxed = nullptr, set_up = nullptr;
+        hipEvent_t pev[3] = { nullptr, nullptr, nullptr };   // timing: plan start, behind the block boxes, behind the plan (on the plan's stream), of this set's LAST plan
+        bool pev_valid = false;
         uint8_t *slab = nullptr;         // one allocation per plan state
         float u_used[32] = {};           // view + proj of the frame whose tile times sit in `feedback` (the plan looks them up through the camera motion)
         bool have_u_used = false;
@@ -317,7 +319,7 @@ struct vf_terrain {
     bool timing = false;
     bool stats_on = false;               // per-item statistics as well (vf_terrain_enable_timing(t, 1)); 2 = device times only
     uint32_t timing_every = 1;           // 3 = device times of every 4th frame only: two event records on the draw stream cost a frame 2 % (tools/exp_timing_cost.py)
-    hipEvent_t ev[kTimingRing][5] = {};   // plan start, after block boxes, after plan (side stream); after tile, before clear (caller's stream)
+    hipEvent_t ev[kTimingRing][5] = {};   // [3] after the tile kernels, [4] before the clear (caller's stream); [0..2] unused since round 6: the plan's events live with its plan state (pev)
     hipEvent_t entry = nullptr;          // caller's stream at render entry (orders a height-cache rebuild after the caller's work)
     uint32_t timed_frames = 0;           // frames recorded since timing was enabled
     hipStream_t last_stream = nullptr;
@@ -632,6 +634,7 @@ void vf_terrain_destroy(vf_terrain *t)
         if (S.drawn) (void)hipEventDestroy(S.drawn);
         if (S.boxed) (void)hipEventDestroy(S.boxed);
         if (S.set_up) (void)hipEventDestroy(S.set_up);
+        for (auto &e : S.pev) if (e) (void)hipEventDestroy(e);
     }
     // (side / side2 / copy_stream belong to the context)
     pinned_free(t->h_stage);
@@ -1126,13 +1129,15 @@ static int plan_frame(vf_terrain *t, hipStream_t s, FramePlan &K, bool ahead = f
     std::memcpy(t->u_drawn, t->u, sizeof t->u_drawn);
     t->have_drawn = true;
     hipStream_t side = solo ? s : t->side, side2 = solo ? s : t->side2;
-    // (a plan queued ahead of its call records no timing events: its frame has no place in the ring yet -- the slot belongs to whatever
-    //  frame is drawn next -- and vf_terrain_timings would pair them with that frame's draw events; draw_frame records them instead)
+    // (the plan's three timing events belong to its plan state, not to a slot of the frame ring: a plan queued ahead of its call has no
+    //  place in the ring yet -- advisor, round 5 -- and the ring's events sit on the draw stream, where every record costs the frame)
     K.sampled = t->timing_every <= 1u || t->frame_no % t->timing_every == 0u;
-    const bool timed = t->timing && !ahead && K.sampled;
-    K.ev_slot = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
-    K.timed = timed;
-    hipEvent_t *ev = t->ev[K.ev_slot];
+    (void)ahead;
+    // (not at timing level 3: an event record between two kernels of the plan chain delays the chain, and a plan that is late holds its frame's
+    //  tile kernel back -- three records per plan cost a C4 frame 2.5 %, on the plan streams as on the draw stream)
+    const bool timed = t->timing && t->timing_every <= 1u && S.pev[0] != nullptr;
+    hipEvent_t *ev = S.pev;
+    S.pev_valid = timed;
     // ---- plan, on the side stream: needs this set back from the frame before last, then touches plan state only ----
     VF_HIP_TRY(hipStreamWaitEvent(side, S.drawn, 0));
     if (t->bounds_dirty) {
@@ -1205,7 +1210,6 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
     const uint32_t slot_now = t->timed_frames % (uint32_t)vf_terrain::kTimingRing;
     hipEvent_t *ev = t->ev[slot_now];
     const bool timing_now = t->timing && K.sampled;
-    if (timing_now && (!K.timed || K.ev_slot != slot_now)) for (int k = 0; k < 3; ++k) VF_HIP_TRY(hipEventRecord(ev[k], s));
     (void)solo;
     // ---- draw, on the caller's stream: everything that touches the output buffers ----
     uint32_t *stats = t->timing && t->stats_on ? t->d_stats : nullptr;
@@ -1385,7 +1389,9 @@ static int render_impl(vf_terrain *t, hipStream_t s, bool write_vis)
     t->last_drawn_gen = t->inputs_gen;
     // the camera is at rest (two frames from one set of inputs), the handle is past its first frames, nothing diagnostic is going on:
     // the next frame's plan goes out now
-    if (again && idle_at_entry && !write_vis && !t->bounds_dirty && !t->camera_moving && !t->was_moving && t->frames_since_reset > vf_terrain::kPlanStates && !(t->timing && t->stats_on)) {
+    // (round 6: also for a caller that streams frames of a resting camera -- its next plan goes out one call early, which changes nothing while
+    //  the frames keep coming and has the plan ready for the first frame after it has waited once)
+    if (again && (idle_at_entry || t->side) && !write_vis && !t->bounds_dirty && !t->camera_moving && !t->was_moving && t->frames_since_reset > vf_terrain::kPlanStates && !(t->timing && t->stats_on)) {
         if (t->side) plan_ahead(t, s);                      // on the plan streams, under this frame's tile kernel
         else t->preplan_pending = true;                     // no plan streams (a waiting caller): behind the next read-back's copy, flush_preplan
     }
@@ -1757,6 +1763,7 @@ int vf_terrain_enable_timing(vf_terrain *t, int enable)
         VF_HIP_TRY(hipSetDevice(t->ctx->device));
         for (auto &f : t->ev) for (auto &e : f) VF_HIP_TRY(hipEventCreate(&e));
     }
+    if (enable != 0) for (auto &S : t->ps) for (auto &e : S.pev) if (!e) VF_HIP_TRY(hipEventCreate(&e));
     if (enable < 0 || enable > 3) return fail(VF_ERR_INVALID, "enable must be 0 .. 3");
     t->timing = enable != 0;
     t->stats_on = enable == 1;   // 2, 3: HIP events only -- the tile kernel runs exactly as it does untimed (no per-item statistics)
@@ -1774,16 +1781,28 @@ int vf_terrain_timings(vf_terrain *t, vf_timings *out)
     // average over the frames recorded since vf_terrain_enable_timing (at most the last kTimingRing)
     const uint32_t nf = t->timed_frames < (uint32_t)vf_terrain::kTimingRing ? t->timed_frames : (uint32_t)vf_terrain::kTimingRing;
     double ranges = 0, plan = 0, tile = 0, total = 0;
+    uint32_t nplan = 0;
     for (uint32_t f = 0; f < nf; ++f) {
-        float a = 0, b = 0, c = 0, d = 0;
+        float c = 0;
         VF_HIP_TRY(hipEventSynchronize(t->ev[f][3]));
-        VF_HIP_TRY(hipEventElapsedTime(&a, t->ev[f][0], t->ev[f][1]));
-        VF_HIP_TRY(hipEventElapsedTime(&b, t->ev[f][1], t->ev[f][2]));
         VF_HIP_TRY(hipEventElapsedTime(&c, t->ev[f][4], t->ev[f][3]));      // clear + tile kernels, on the caller's stream
-        VF_HIP_TRY(hipEventElapsedTime(&d, t->ev[f][0], t->ev[f][3]));
-        ranges += a; plan += b; tile += c; total += d;
+        tile += c; total += c;
     }
-    out->ranges_ms = (float)(ranges / nf); out->plan_ms = (float)(plan / nf); out->tile_ms = (float)(tile / nf);
+    // the plan chain: the last plan of each plan state (the frames drawn last, or the plan queued ahead of the next call)
+    VF_HIP_TRY(sync_sides(t));
+    for (auto &S : t->ps) {
+        if (!S.pev_valid || !S.pev[2]) continue;
+        float a = 0, b = 0;
+        if (hipEventSynchronize(S.pev[2]) != hipSuccess || hipEventElapsedTime(&a, S.pev[0], S.pev[1]) != hipSuccess ||
+            hipEventElapsedTime(&b, S.pev[1], S.pev[2]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        ranges += a; plan += b; ++nplan;
+    }
+    if (nf == 1u && t->ps[t->last_set].pev_valid) {         // a single timed frame: plan start -> RGBA8 complete
+        float d = 0;
+        if (hipEventElapsedTime(&d, t->ps[t->last_set].pev[0], t->ev[0][3]) == hipSuccess && d > 0.0f) total = d;
+        else (void)hipGetLastError();
+    }
+    out->ranges_ms = nplan ? (float)(ranges / nplan) : 0.0f; out->plan_ms = nplan ? (float)(plan / nplan) : 0.0f; out->tile_ms = (float)(tile / nf);
     out->total_ms = (float)(total / nf);
     if (nf >= 2 && t->timed_frames <= (uint32_t)vf_terrain::kTimingRing) {
         // frames rendered back to back overlap (frame f+1 plans while frame f draws): the frame period is what a frame costs
