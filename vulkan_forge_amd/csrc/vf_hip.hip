@@ -1266,7 +1266,10 @@ static int draw_frame(vf_terrain *t, hipStream_t s, const FramePlan &K, bool wri
         if (e < kSettle) pick = guess;
         else if (e < kSettle + kProbe) pick = guess ^ abba(e - kSettle);
         else if (t->g_n[0] && t->g_n[1]) {
-            pick = t->g_ms[1] <= t->g_ms[0] ? 1 : 0;
+            // (round 6: the default variant stays unless the other one measured CLEARLY faster, 3 %.  Where the choice matters the two are
+            //  5-17 % apart -- profiles/r06_line_loops.log -- but a probed frame carries two event records and reads 10 % high, and two
+            //  noisy means 0.01 % apart once made a C4 handle draw with the strip variant: 0.787 ms instead of 0.723)
+            pick = t->g_ms[guess ^ 1] < 0.97f * t->g_ms[guess] ? (guess ^ 1) : guess;
             if (e % kAgain >= kAgain - 4u) pick ^= abba(e % kAgain - (kAgain - 4u)) ^ 1;      // B A A B seen from the variant in use: two frames of the other one
         }
         // (no samples yet -- a host that queues frames faster than the GPU draws them is past the window before its first probe
