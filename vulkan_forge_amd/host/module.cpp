@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
 
 #include "../../include/vf_hip.h"
 #include "../data/colormaps_rgba8.h"
@@ -294,6 +295,17 @@ public:
         // frame-sized: the array lives in page-locked memory from the pool (above) -- one DMA transfer, no host copy
         void *p = PinnedPool::get().take_or_null(bytes, 3 * bytes);
         if (!p) {                                                // (the caller keeps its frames: ordinary arrays from here on)
+            // ... in huge pages where the host has them: the copy out of the pinned ring into a fresh array is page-fault bound, and a
+            // 2 MiB page takes one fault where 4 KiB pages take 512
+            constexpr size_t kHuge = (size_t)2 << 20;
+            void *q = nullptr;
+            const size_t r = (bytes + kHuge - 1) & ~(kHuge - 1);
+            if (posix_memalign(&q, kHuge, r) == 0) {
+                (void)madvise(q, r, MADV_HUGEPAGE);
+                py::capsule owner(q, [](void *v) { std::free(v); });
+                render_into(static_cast<uint8_t *>(q), rows);
+                return py::array_t<uint8_t>({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 }, static_cast<uint8_t *>(q), owner);
+            }
             py::array_t<uint8_t> a({ (py::ssize_t)rows, (py::ssize_t)W, (py::ssize_t)4 });
             render_into(a.mutable_data(), rows);
             return a;
